@@ -1,0 +1,161 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.npz by RUNNING THE COMPILED REFERENCE (oracle/_ref).
+
+Container-only: needs /root/reference (to build oracle/_ref via `make -C oracle ref`).
+The committed .npz files hold data only — inputs (seeds, key sequences) and the outputs the
+reference produced (per-step records in the oracle.RECORD layout; fields the reference cannot
+show stay zero and are listed in ref_driver.HIDDEN/VISIBLE).  No reference source is stored.
+
+    python tests/golden/make_golden.py            # regenerate everything
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from oracle import oracle as orc  # noqa: E402
+from tests.golden.policies import GreedyRT, rt_keys  # noqa: E402
+from tests.golden.ref_driver import RefGame  # noqa: E402
+
+MAXK = 32
+
+
+def record_trace(name, P, H, pieces, seed0, steps, policy, sloppiness=0.0, early_reset_every=0):
+    """One game driven for `steps` env-steps; reset with seed0 + 17*episode on done."""
+    rng = np.random.default_rng(abs(hash((name, seed0))) % (2**32))
+    ref = RefGame(P, H, 10, pieces=pieces, seed=seed0)
+    shadow = orc.OracleBatch(1, P, H, 10, pieces=pieces, seeds=seed0)   # only feeds the greedy policy
+    greedy = GreedyRT(P, H, pieces=pieces, sloppiness=sloppiness, seed=seed0) if policy == "greedy" else None
+
+    ev_kind, ev_seed, ev_player, ev_keys, ev_len, ev_done = [], [], [], [], [], []
+    recs, ro, lw = [], [], []
+
+    def snap():
+        r, o, w = ref.record()
+        recs.append(r); ro.append(o); lw.append(w)
+
+    def do_reset(seed):
+        ref.reset(seed); shadow.reset(seeds=seed)
+        ev_kind.append(0); ev_seed.append(seed); ev_player.append(0)
+        ev_keys.append(np.zeros(MAXK, np.uint8)); ev_len.append(0); ev_done.append(0)
+        snap()
+
+    # event 0: state right after construction (PythonHandle ctor with time()==seed0)
+    ev_kind.append(2); ev_seed.append(seed0); ev_player.append(0)
+    ev_keys.append(np.zeros(MAXK, np.uint8)); ev_len.append(0); ev_done.append(0)
+    snap()
+    do_reset(seed0)     # tetris_environment.__init__ always resets once (tetris_environment.py:40-41)
+    episode = 0
+    for s in range(steps):
+        player = s % P
+        if policy == "rt":
+            keys = rt_keys(rng.integers(4), rng.integers(10))
+        elif policy == "keys":
+            keys = list(rng.integers(0, 11, size=rng.integers(0, 14)))
+            if rng.random() < 0.75:
+                keys.append(7)
+            if rng.random() < 0.05:
+                keys += [int(rng.integers(8, 11)), 7]      # keys after a lock
+        elif policy == "greedy":
+            keys = rt_keys(*greedy.choose(shadow, 0, player))
+        elif policy == "drop":
+            keys = [7]
+        else:
+            raise ValueError(policy)
+        keys = [int(k) for k in keys][:MAXK]
+        done = ref.step(keys, player)
+        K = np.zeros((1, P, MAXK), np.uint8); L = np.ones((1, P), np.uint8)
+        K[0, player, : len(keys)] = keys; L[0, player] = len(keys)
+        shadow.make_actions(K, L); shadow.finish_actions(400)
+        kk = np.zeros(MAXK, np.uint8); kk[: len(keys)] = keys
+        ev_kind.append(1); ev_seed.append(0); ev_player.append(player)
+        ev_keys.append(kk); ev_len.append(len(keys)); ev_done.append(int(done))
+        snap()
+        if done or (early_reset_every and s % early_reset_every == early_reset_every - 1):
+            episode += 1
+            do_reset(seed0 + 17 * episode)
+    out = dict(
+        n_players=P, height=H, width=10, pieces=np.array((list(pieces) * 7)[:7], np.uint8), ms=400,
+        ev_kind=np.array(ev_kind, np.uint8),          # 2 = constructed, 0 = reset(seed), 1 = step
+        ev_seed=np.array(ev_seed, np.int64), ev_player=np.array(ev_player, np.uint8),
+        ev_keys=np.stack(ev_keys), ev_len=np.array(ev_len, np.uint8), ev_done=np.array(ev_done, np.uint8),
+        records=np.stack(recs), round_over=np.array(ro, np.uint8), last_winner=np.array(lw, np.int8),
+    )
+    path = os.path.join(HERE, f"trace_{name}.npz")
+    np.savez_compressed(path, **out)
+    cleared = int(out["records"]["reward"][out["ev_kind"] == 1].sum())
+    print(f"{name}: {len(ev_kind)} events, {episode} resets, {cleared} lines, {os.path.getsize(path) / 1024:.0f} KiB")
+
+
+def rotation_table():
+    """All 7 pieces: spawn state, then cw x4, ccw x4, 180 x2 on an empty 20x10 board, at spawn and
+    pushed against both walls (kick table, gameField.cpp:55-103)."""
+    rows = []
+    for piece in range(7):
+        for prefix in ([], [2], [4], [2, 3], [4, 1]):
+            for seq in ([8] * 4, [9] * 4, [10] * 2, [8, 10, 9], [5, 5, 8, 9, 10]):
+                g = RefGame(1, 20, 10, pieces=[piece], seed=3)
+                g.reset(3)
+                for k in prefix:
+                    g.make([[k]])
+                for k in seq:
+                    g.make([[k]])
+                    r, _, _ = g.record()
+                    rows.append((piece, len(prefix) and prefix[0], k, int(r["x"][0]), int(r["y"][0]), int(r["cur_rot"][0]),
+                                 r["grid"][0].copy()))
+    arr = np.zeros(len(rows), dtype=[("piece", "u1"), ("prefix", "u1"), ("key", "u1"), ("x", "i1"), ("y", "i1"), ("rot", "u1"), ("grid", "u1", (4, 4))])
+    for i, row in enumerate(rows):
+        arr[i] = row
+    return arr
+
+
+def rng_kat():
+    """First pieces per seed for several piece sets (randomizer.cpp:10-62, gamePlay.cpp:218-230)."""
+    out = {}
+    for tag, pieces in (("all", [0, 1, 2, 3, 4, 5, 6]), ("sz", [2, 3]), ("i", [4]), ("lj", [0, 1])):
+        seeds = [1000, 0, 1, -1, -5, 12345, 32767, -32768, 40000, 66536]
+        seq = np.zeros((len(seeds), 40), np.uint8)
+        for i, sd in enumerate(seeds):
+            g = RefGame(1, 20, 10, pieces=pieces, seed=sd)
+            g.reset(sd)
+            r, _, _ = g.record()
+            cur = {4: 0, 3: 1, 5: 2, 7: 3, 2: 4, 1: 5, 6: 6}[int(r["grid"][0].max())]
+            seq[i, 0], seq[i, 1] = cur, r["next"][0]
+            for j in range(2, 40):
+                g.make([[1]])        # never locks: board stays empty, every finish deals a new piece
+                g.finish(400)
+                seq[i, j] = g.record()[0]["next"][0]
+        out[f"seeds_{tag}"] = np.array(seeds, np.int64)
+        out[f"pieces_{tag}"] = seq
+    return out
+
+
+def main():
+    orc.build()
+    if not orc.ref_available():
+        sys.exit("oracle/_ref is not built and /root/reference is absent: cannot generate fixtures here")
+    allp = [0, 1, 2, 3, 4, 5, 6]
+    record_trace("rt_1p", 1, 20, allp, 1000, 1500, "rt")
+    record_trace("rt_2p", 2, 20, allp, 1000, 2500, "rt", early_reset_every=333)
+    record_trace("rt_2p_neg", 2, 20, allp, -5, 1200, "rt")
+    record_trace("keys_1p", 1, 20, allp, 40000, 1500, "keys")
+    record_trace("keys_2p", 2, 20, allp, 7, 2500, "keys")
+    record_trace("keys_2p_22", 2, 22, allp, 31000, 1500, "keys")
+    record_trace("greedy_1p", 1, 20, allp, 1000, 3000, "greedy")
+    record_trace("greedy_2p", 2, 20, allp, 1000, 3000, "greedy", sloppiness=0.05)
+    record_trace("greedy_2p_b", 2, 22, allp, 77, 2500, "greedy", sloppiness=0.15)
+    record_trace("greedy_1p_io", 1, 20, [4, 6], 9, 1500, "greedy", sloppiness=0.02)
+    record_trace("greedy_2p_o", 2, 20, [6], 11, 1500, "greedy", sloppiness=0.02)
+    record_trace("rt_2p_sz", 2, 20, [2, 3], 5, 800, "rt")
+    record_trace("drop_2p", 2, 20, allp, 1000, 120, "drop")
+    np.savez_compressed(os.path.join(HERE, "rotation_table.npz"), table=rotation_table())
+    np.savez_compressed(os.path.join(HERE, "rng_kat.npz"), **rng_kat())
+    print("done")
+
+
+if __name__ == "__main__":
+    main()

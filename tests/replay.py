@@ -1,0 +1,69 @@
+"""Replays a golden trace (tests/golden/trace_*.npz, produced by the compiled reference) through
+any engine exposing reset / make_actions / finish_actions / observe, and compares every field
+the reference can show, event by event.  Shared by the oracle tests (CPU) and the HIP tests (GPU)."""
+import glob
+import os
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+# what the compiled reference exposes (see tests/golden/ref_driver.py)
+VISIBLE = ["field", "grid", "x", "y", "next", "dead", "reward", "inc_count", "combo_count", "combo_remaining"]
+HIDDEN = ["spawn_rot", "cur_rot", "big", "tile", "piece", "lines_sent", "lines_cleared", "lines_blocked", "max_combo",
+          "fifo_len", "fifo_count", "fifo_delay", "min_remaining", "drop_delay", "drop_time", "speedup_time",
+          "lock_time", "lock_armed", "time_ms", "incoming", "lines_cleared_seen"]
+COLOUR_ONLY = ["garbage_cleared"]      # needs cell colours (8 = garbage)
+
+
+def trace_names():
+    return sorted(os.path.basename(p)[len("trace_"):-len(".npz")] for p in glob.glob(os.path.join(GOLDEN, "trace_*.npz")))
+
+
+def load_trace(name):
+    return np.load(os.path.join(GOLDEN, f"trace_{name}.npz"))
+
+
+def compare(got, want, fields, occupancy_only=False, where=""):
+    for f in fields:
+        a, b = got[f], want[f]
+        if f == "field" and occupancy_only:
+            a, b = a > 0, b > 0
+        if not np.array_equal(a, b):
+            raise AssertionError(f"{where}: field '{f}' differs\n got  {a.tolist() if a.size < 64 else a}\n want {b.tolist() if b.size < 64 else b}")
+
+
+def replay(trace, make_engine, fields=None, occupancy_only=False, max_events=None):
+    """make_engine(n_players, height, width, pieces, seed) -> engine with one game."""
+    P, H = int(trace["n_players"]), int(trace["height"])
+    fields = fields or (VISIBLE + HIDDEN)
+    kinds, seeds, players = trace["ev_kind"], trace["ev_seed"], trace["ev_player"]
+    keys, lens, dones = trace["ev_keys"], trace["ev_len"], trace["ev_done"]
+    want, want_ro, want_lw = trace["records"], trace["round_over"], trace["last_winner"]
+    eng = None
+    first_step_seen = False
+    n = len(kinds) if max_events is None else min(len(kinds), max_events)
+    for e in range(n):
+        k = int(kinds[e])
+        if k == 2:
+            eng = make_engine(P, H, int(trace["width"]), trace["pieces"].tolist(), int(seeds[e]))
+        elif k == 0:
+            eng.reset(None, seeds=int(seeds[e]))
+        else:
+            K = np.zeros((1, P, keys.shape[1]), np.uint8)
+            L = np.ones((1, P), np.uint8)        # the other players get [0] (tetris_environment.py:106-108)
+            K[0, players[e], :] = keys[e]
+            L[0, players[e]] = lens[e]
+            eng.make_actions(K, L)
+            done = eng.finish_actions(int(trace["ms"]))
+            assert bool(done[0]) == bool(dones[e]), f"event {e}: done {done[0]} != {dones[e]}"
+        rec, ro, lw = eng.observe()
+        fs = fields
+        if not first_step_seen:
+            # ComboCounter::remaining is uninitialised until the first finish_action
+            fs = [f for f in fields if f != "combo_remaining"]
+            first_step_seen = k == 1
+        compare(rec[0], want[e], fs, occupancy_only, where=f"event {e} (kind {k})")
+        assert int(ro[0]) == int(want_ro[e]), f"event {e}: round_over"
+        assert int(lw[0]) == int(want_lw[e]), f"event {e}: last_winner {lw[0]} != {want_lw[e]}"
+    return n
