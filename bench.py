@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: env-steps/s of seeded random-policy rollouts.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one launch of the rollout kernel = ONE env-step on every game of the batch (state is
+read from HBM, stepped, auto-reset where done, written back).  N=1 workload = BASELINE.json
+configs[1]: 65 536 parallel 20x10 single-player boards, random (rotation, translation) policy.
+For N>1 (launched by torch.distributed.run, one rank per GPU) every rank owns its own 65 536 games:
+games never interact across ranks, so there is no data-path collective ("scaling": "weak").
+
+Prints ONE JSON line (rank 0).  `value` = env-steps of all ranks / max-over-ranks wall time of the
+K timed launches, inputs resident in HBM.  `roofline` prices the step kernel against the 8 TB/s HBM
+roofline with SURVEY §8(d)'s algorithmic bytes (389 B per 1-player env-step, 774 B per 2-player one)
+and the kernel's average launch duration measured with HIP events on the launch stream.
+`cpu_baseline` times the reference C++ backend itself (oracle/_ref, built in the container from
+/root/reference) or, without it, the C restatement, on the host cores of this box.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import __graft_entry__ as ge  # noqa: E402
+
+ALGO_BYTES = {1: 389, 2: 774}       # P*(192 read + 192 write) + 2 action + (P+2) outputs
+HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def cpu_baseline(n_players, height, budget_s):
+    """Reference (or port) env-steps/s on this box's host cores, bounded sample of the same workload."""
+    from oracle import oracle as orc
+
+    out = {}
+    n = 32
+    if orc.ref_available():
+        # the compiled reference backend driven like tetris_environment.perform_action does
+        # (make_action + finish_action, reset when done), single thread, 32 envs round-robin
+        mod, set_time = orc.ref_module()
+        mod.set_pieces([0, 1, 2, 3, 4, 5, 6])
+        envs = []
+        for g in range(n):
+            set_time(int(orc.episode_seed(g, 0)))
+            envs.append(mod.PythonHandle(n_players, [height, 10]))
+        episode = [0] * n
+        steps = 0
+        t0 = time.perf_counter()
+        s = 0
+        while time.perf_counter() - t0 < budget_s:
+            for g, h in enumerate(envs):
+                w = orc.philox(0xD71, 0, g, s & 0xFFFFFFFF, s >> 32, 0)
+                keys = [8] * int(w[0] & 3) + [2] + [3] * int(w[1] % 10) + [7]
+                a = [[0] for _ in range(n_players)]
+                a[s % n_players] = keys
+                h.make_action(a)
+                if h.finish_action(400):
+                    episode[g] += 1
+                    set_time(int(orc.episode_seed(g, episode[g])))
+                    h.reset()
+            s += 1
+            steps += n
+        dt = time.perf_counter() - t0
+        out = {"value": steps / dt, "unit": "env-steps/s", "cores": 1, "kind": "reference",
+               "sample": f"reference C++ backend (oracle/_ref, -O0 as the reference builds it), {n} envs x {s} steps, "
+                         f"{n_players} player(s), {height}x10, same policy/seeds, bare make_action+finish_action+reset loop from Python"}
+    # the C restatement (port), one thread and all cores
+    cores = os.cpu_count() or 1
+    nb = 4096
+    b = orc.OracleBatch(nb, n_players, height, 10, seeds=orc.episode_seed(np.arange(nb), 0))
+    port = {}
+    for threads in (1, cores):
+        ep = np.zeros(nb, np.uint32)
+        t0 = time.perf_counter()
+        done_steps = 0
+        first = 0
+        while time.perf_counter() - t0 < max(1.0, budget_s / 4):
+            b.rollout_random(16, first_step=first, episode=ep, threads=threads)
+            first += 16
+            done_steps += 16 * nb
+        port[threads] = done_steps / (time.perf_counter() - t0)
+    if not out:
+        out = {"value": port[cores], "unit": "env-steps/s", "cores": cores, "kind": "port",
+               "sample": f"oracle C restatement, {nb} envs, OpenMP over envs"}
+    out["port_1_thread"] = port[1]
+    out["port_all_cores"] = {"value": port[cores], "cores": cores}
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2048)
+    ap.add_argument("--warmup", type=int, default=64)
+    ap.add_argument("--games", type=int, default=65536, help="games per GPU")
+    ap.add_argument("--players", type=int, default=1)
+    ap.add_argument("--height", type=int, default=20)
+    ap.add_argument("--steps-per-launch", type=int, default=1, help=">1 = fused rollout (state stays in registers)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if args.gpus != world and rank == 0 and world > 1:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+
+    pkg = ge.package()
+    N, P, S = args.games, args.players, args.steps_per_launch
+    # rank r owns global games [r*N, (r+1)*N): distinct seed schedule per rank
+    seeds = None
+    from_game = rank * N
+    seeds = ((12345 + 7919 * (np.arange(N, dtype=np.int64) + from_game)) & 0xFFFF).astype(np.uint16).view(np.int16)
+    batch = pkg.TetrisBatch(N, P, args.height, 10, seeds=seeds, device=local_rank)
+    batch.set_game_offset(from_game)
+
+    def sync_all():
+        if dist is not None:
+            import torch
+            dist.barrier()
+            torch.cuda.synchronize()
+        batch.sync()
+
+    # warm-up (untimed)
+    first = 0
+    if args.warmup > 0:
+        batch.rollout_random(args.warmup, S, first_step=first)
+        first += args.warmup * S
+    sync_all()
+    t0 = time.perf_counter()
+    counters, ev_ms = batch.rollout_random(args.steps, S, first_step=first)
+    sync_all()
+    wall = time.perf_counter() - t0
+
+    if dist is not None:
+        import torch
+        t = torch.tensor([wall, ev_ms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall, ev_ms = float(t[0]), float(t[1])
+        c = torch.tensor([int(x) for x in counters], dtype=torch.int64, device="cuda")
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        counters = c.cpu().numpy()
+
+    if rank == 0:
+        env_steps = int(counters[0])
+        assert env_steps == world * N * S * args.steps, (env_steps, world, N, S, args.steps)
+        launch_us = ev_ms * 1e3 / args.steps                      # HIP events on the launch stream
+        algo_bytes = ALGO_BYTES[P] * N * S                        # per launch, per GPU
+        achieved = algo_bytes / (launch_us * 1e-6) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", f"pmc_p{P}_s{S}.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "env-steps/sec at 64k parallel 20x10 boards",
+            "value": env_steps / wall,
+            "unit": "env-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": wall * 1e3 / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{N} parallel {args.height}x10 {'single' if P == 1 else 'two'}-player boards per GPU, "
+                            f"random (rotation,translation) policy, auto-reset, {S} env-step(s) per launch",
+                "games_per_gpu": N, "players": P, "steps_per_launch": S, "parallelism": f"replicas x{world} (no collective)",
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic, "kernel": f"k_game<{P}, M_ROLLOUT>", "algorithmic_bytes_per_launch": algo_bytes,
+                "launch_us": launch_us,
+            },
+            "episodes": int(counters[1]), "lines_cleared": int(counters[2]), "garbage_sent": int(counters[3]),
+        }
+        if args.cpu_seconds > 0 and world == 1:
+            line["cpu_baseline"] = cpu_baseline(P, args.height, args.cpu_seconds)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line))
+    batch.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,225 @@
+"""ctypes binding of libtetris_hip.so (include/tetris_hip.h) — the thin shim between the Python
+host code and the HIP kernels.
+
+The library is loaded from ``drl-tetris_amd/lib/libtetris_hip.so`` (built in-tree by
+``__graft_entry__.build()``).  There is no CPU path: if the library is missing, or no HIP device is
+present, creating a batch raises ``TetrisError``.  (``lib_path`` exists so that the test suite can
+point the same binding at its CPU test harness; product code never passes it.)
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(HERE, "lib", "libtetris_hip.so")
+
+MAX_H, W, FIFO_CAP = 32, 10, 16
+
+# mirrors `struct tetris_record` (include/tetris_hip.h)
+RECORD = np.dtype(
+    [
+        ("field", np.uint8, (MAX_H, W)), ("grid", np.uint8, (4, 4)), ("x", np.int8), ("y", np.int8),
+        ("piece", np.uint8), ("tile", np.uint8), ("spawn_rot", np.uint8), ("cur_rot", np.uint8), ("big", np.uint8),
+        ("next", np.uint8), ("dead", np.uint8), ("reward", np.uint8), ("inc_count", np.uint8), ("combo_count", np.uint8),
+        ("combo_remaining", np.uint16), ("lock_armed", np.uint8), ("fifo_len", np.uint8), ("line_count", np.uint8),
+        ("fifo_overflow", np.uint8), ("time_ms", np.int32), ("incoming", np.float32), ("drop_delay", np.int32),
+        ("drop_time", np.int32), ("speedup_time", np.int32), ("lock_time", np.int32), ("min_remaining", np.int32),
+        ("combo_start", np.int32), ("combo_time", np.int32), ("fifo_delay", np.int32, (FIFO_CAP,)),
+        ("fifo_count", np.int16, (FIFO_CAP,)), ("lines_sent", np.uint16), ("lines_cleared", np.uint16),
+        ("lines_blocked", np.uint16), ("garbage_cleared", np.uint16), ("max_combo", np.uint16),
+        ("lines_cleared_seen", np.uint16), ("weights", np.float32, (7,)), ("piece_draws", np.uint32),
+        ("hole_draws", np.uint32),
+    ],
+    align=True,
+)
+
+
+class TetrisError(RuntimeError):
+    pass
+
+
+_libs = {}
+
+_SIGNATURES = {
+    "tetris_last_error": (C.c_char_p, []),
+    "tetris_device_count": (C.c_int, []),
+    "tetris_record_size": (C.c_int, []),
+    "tetris_layout_words": (C.c_int, []),
+    "tetris_snapshot_words": (C.c_int, [C.c_void_p]),
+    "tetris_table_chunks": (C.c_int, [C.c_void_p]),
+    "tetris_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "tetris_destroy": (C.c_int, [C.c_void_p]),
+    "tetris_sync": (C.c_int, [C.c_void_p]),
+    "tetris_set_game_offset": (C.c_int, [C.c_void_p, C.c_uint64]),
+    "tetris_reset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "tetris_make_actions": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
+    "tetris_finish_actions": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "tetris_step_keys": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "tetris_step_rt": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "tetris_step_rt_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "tetris_observe_records": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "tetris_snapshot": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "tetris_restore": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "tetris_set_dead": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "tetris_rollout_random": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_uint32, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p]),
+    "tetris_device_state": (C.c_void_p, [C.c_void_p]),
+    "tetris_stream": (C.c_void_p, [C.c_void_p]),
+}
+
+EXPORTS = tuple(_SIGNATURES)
+
+
+def load_library(lib_path=None):
+    path = os.path.abspath(lib_path or DEFAULT_LIB)
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
+        raise TetrisError(f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    lib = C.CDLL(path)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here = the library does not export the ABI
+        fn.restype, fn.argtypes = res, args
+    if lib.tetris_record_size() != RECORD.itemsize:
+        raise TetrisError("tetris_record layout mismatch between the library and capi.RECORD")
+    _libs[path] = lib
+    return lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _u8(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    if shape is not None and a.shape != shape:
+        raise ValueError(f"expected shape {shape}, got {a.shape}")
+    return a
+
+
+class TetrisBatch:
+    """N games resident on one GPU (one `tetris_batch`)."""
+
+    def __init__(self, n_games, n_players=2, height=20, width=10, pieces=(0, 1, 2, 3, 4, 5, 6), seeds=None, device=0, lib_path=None):
+        self.lib = load_library(lib_path)
+        self.n_games, self.n_players, self.height, self.width = int(n_games), int(n_players), int(height), int(width)
+        self.piece_map = np.array((list(pieces) * 7)[:7], dtype=np.uint8)      # tetris_environment.py:191-193
+        self._h = C.c_void_p()
+        s = self._seeds(seeds, self.n_games) if seeds is not None else None
+        self._check(self.lib.tetris_create(C.byref(self._h), self.n_games, self.n_players, self.height, self.width,
+                                           _p(self.piece_map), int(device), _p(s)))
+        self.snapshot_words = self.lib.tetris_snapshot_words(self._h)
+
+    # -- plumbing
+    def _check(self, rc):
+        if rc != 0:
+            raise TetrisError(f"libtetris_hip error {rc}: {self.lib.tetris_last_error().decode()}")
+
+    @staticmethod
+    def _seeds(seeds, n):
+        # randomizer.cpp:34-36: seeds are truncated to `short`
+        return np.ascontiguousarray(np.broadcast_to(np.asarray(seeds), (n,)).astype(np.int64).astype(np.int16))
+
+    def _idx(self, idx):
+        if idx is None:
+            return None, self.n_games
+        a = np.ascontiguousarray(idx, dtype=np.int32).reshape(-1)
+        return a, len(a)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self.lib.tetris_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- the reference's PythonHandle surface, batched
+    def reset(self, idx=None, seeds=0):
+        a, n = self._idx(idx)
+        self._check(self.lib.tetris_reset(self._h, _p(a), n, _p(self._seeds(seeds, n))))
+
+    def make_actions(self, keys, lens, idx=None):
+        a, n = self._idx(idx)
+        keys = _u8(keys)
+        lens = _u8(lens, (n, self.n_players))
+        if keys.ndim != 3 or keys.shape[:2] != (n, self.n_players):
+            raise ValueError("keys must be [n, P, max_keys]")
+        self._check(self.lib.tetris_make_actions(self._h, _p(a), n, _p(keys), _p(lens), keys.shape[2]))
+
+    def finish_actions(self, ms=400, idx=None, full=False):
+        a, n = self._idx(idx)
+        done = np.zeros(n, np.uint8)
+        lines = np.zeros((n, self.n_players), np.uint8)
+        dead = np.zeros((n, self.n_players), np.uint8)
+        self._check(self.lib.tetris_finish_actions(self._h, _p(a), n, int(ms), _p(done), _p(lines), _p(dead)))
+        return (done, lines, dead) if full else done
+
+    def step_keys(self, keys, lens, ms=400, idx=None):
+        a, n = self._idx(idx)
+        keys = _u8(keys)
+        lens = _u8(lens, (n, self.n_players))
+        if keys.ndim != 3 or keys.shape[:2] != (n, self.n_players):
+            raise ValueError("keys must be [n, P, max_keys]")
+        done = np.zeros(n, np.uint8)
+        lines = np.zeros((n, self.n_players), np.uint8)
+        dead = np.zeros((n, self.n_players), np.uint8)
+        self._check(self.lib.tetris_step_keys(self._h, _p(a), n, _p(keys), _p(lens), keys.shape[2], int(ms), _p(done), _p(lines), _p(dead)))
+        return done, lines, dead
+
+    def step_rt(self, rot, trans, player=None, ms=400, full=False):
+        n = self.n_games
+        rot, trans = _u8(rot, (n,)), _u8(trans, (n,))
+        pl = None if player is None else _u8(np.broadcast_to(player, (n,)))
+        done = np.zeros(n, np.uint8)
+        lines = np.zeros((n, self.n_players), np.uint8)
+        dead = np.zeros((n, self.n_players), np.uint8)
+        self._check(self.lib.tetris_step_rt(self._h, _p(rot), _p(trans), _p(pl), int(ms), _p(done), _p(lines), _p(dead)))
+        return (done, lines, dead) if full else done
+
+    def observe(self, idx=None):
+        a, n = self._idx(idx)
+        rec = np.zeros((n, self.n_players), dtype=RECORD)
+        ro = np.zeros(n, np.uint8)
+        lw = np.zeros(n, np.int8)
+        self._check(self.lib.tetris_observe_records(self._h, _p(a), n, _p(rec), _p(ro), _p(lw)))
+        return rec, ro, lw
+
+    def snapshot(self, idx=None):
+        a, n = self._idx(idx)
+        blob = np.zeros((n, self.snapshot_words), np.uint32)
+        self._check(self.lib.tetris_snapshot(self._h, _p(a), n, _p(blob)))
+        return blob
+
+    def restore(self, blob, idx=None):
+        a, n = self._idx(idx)
+        blob = np.ascontiguousarray(blob, dtype=np.uint32)
+        if blob.shape != (n, self.snapshot_words):
+            raise ValueError(f"blob must be [{n}, {self.snapshot_words}]")
+        self._check(self.lib.tetris_restore(self._h, _p(a), n, _p(blob)))
+
+    def set_dead(self, dead, idx=None):
+        a, n = self._idx(idx)
+        self._check(self.lib.tetris_set_dead(self._h, _p(a), n, _p(_u8(dead, (n, self.n_players)))))
+
+    def rollout_random(self, launches, steps_per_launch=1, policy_seed=0xD71, first_step=0, ms=400):
+        """-> (counters[4] = env_steps, episodes, lines, sent; elapsed_ms on the batch's stream)"""
+        counters = np.zeros(4, np.uint64)
+        elapsed = C.c_float(0.0)
+        self._check(self.lib.tetris_rollout_random(self._h, int(launches), int(steps_per_launch), int(policy_seed), int(first_step),
+                                                   int(ms), _p(counters), C.byref(elapsed)))
+        return counters, float(elapsed.value)
+
+    def set_game_offset(self, first_game_id):
+        self._check(self.lib.tetris_set_game_offset(self._h, int(first_game_id)))
+
+    def sync(self):
+        self._check(self.lib.tetris_sync(self._h))
+
+    @property
+    def table_chunks(self):
+        return self.lib.tetris_table_chunks(self._h)

@@ -1,0 +1,662 @@
+// Per-game step logic of the MI355X batched Tetris environment — one game per lane, boards as
+// packed uint32 column bitboards.  Written from the behavioural spec in SURVEY.md App. A/B; every
+// function cites the reference file:line (relative to
+// /root/reference/environment/game_backend/source/) whose observable behaviour it must reproduce.
+//
+// This header is `__host__ __device__`.  The product compiles it with hipcc for gfx950 only
+// (tetris_hip.hip); tests/cpu_harness compiles the very same source with g++ so the logic can be
+// checked against the oracle without a GPU.  There is no CPU path in the shipped library.
+//
+// Bitboard conventions
+//   col[c]            bit y = 1  <=>  square (row y, column c) is occupied; row 0 is the top.
+//   floor             bits >= H of every column read as 1 (added in registers, never stored).
+//   shape "colnibs"   16 bits, nibble gx = the piece's column gx of its 4x4 grid, bit gy = row gy.
+//   band window B(y)  64 bits, nibble (c+2) = rows y..y+3 of column c; nibbles 0,1,12..15 = 0xF
+//                     (walls).  A piece at (x,y) fits  <=>  ((colnibs << 4(x+2)) & B(y)) == 0.
+//                     One 64-bit AND per collision test; sideways moves only change the shift.
+#pragma once
+#include "tetris_layout.h"
+#include "tetris_tables.h"
+
+#if defined(__clang__)
+#define TE_UNROLL _Pragma("unroll")
+#else
+#define TE_UNROLL _Pragma("GCC unroll 8")
+#endif
+
+namespace te {
+
+// ---------------------------------------------------------------- small helpers
+#if defined(__HIP_DEVICE_COMPILE__)
+TE_HD int ctz32(uint32_t v) { return __builtin_ctz(v); }
+TE_HD int clz32(uint32_t v) { return __builtin_clz(v); }
+#else
+TE_HD int ctz32(uint32_t v) { return __builtin_ctz(v); }
+TE_HD int clz32(uint32_t v) { return __builtin_clz(v); }
+#endif
+TE_HD int imin(int a, int b) { return a < b ? a : b; }
+TE_HD int imax(int a, int b) { return a > b ? a : b; }
+TE_HD uint32_t f2u(float f) { union { float f; uint32_t u; } v; v.f = f; return v.u; }
+TE_HD float u2f(uint32_t u) { union { float f; uint32_t u; } v; v.u = u; return v.f; }
+
+// ---------------------------------------------------------------- shapes
+// SURVEY.md App. B (probed against the reference for all 28 states): rows y0..y3 as hex nibbles,
+// bit x = column x, indexed [piece][current_rotation].  Restates the templates + spawn rotations of
+// gamePlay.cpp:116-158 and the raw 3x3/4x4 rotation of pieces.cpp:5-53 as a table.
+constexpr uint16_t SHAPE_ROWS[7][4] = {
+    {0x2260, 0x0710, 0x3220, 0x4700}, {0x2230, 0x1700, 0x6220, 0x0740}, {0x2640, 0x0630, 0x1320, 0x6300},
+    {0x2310, 0x3600, 0x4620, 0x0360}, {0x2222, 0x0f00, 0x4444, 0x00f0}, {0x0720, 0x2320, 0x2700, 0x2620},
+    {0x0660, 0x0660, 0x0660, 0x0660},
+};
+// spawn rotations {3,1,3,1,1,2,0} (gamePlay.cpp:117) and piece-grid values {4,3,5,7,2,1,6}
+// (gamePlay.cpp:125-139), packed so that a per-lane lookup is a shift instead of a memory read
+TE_HD int spawn_rot(int kind) { return (int)((0x0977u >> (2 * (kind & 7))) & 3u); }
+TE_HD int shape_value(int kind) { return (int)((0x06127534u >> (4 * (kind & 7))) & 15u); }
+
+// shape word: colnibs[0:16) | first occupied column[16:18) | last occupied column[18:20)
+constexpr uint32_t make_shape(int kind, int rot) {
+    uint32_t rows = SHAPE_ROWS[kind][rot];
+    uint32_t nibs = 0;
+    for (int gy = 0; gy < 4; gy++) {
+        uint32_t rown = (rows >> (4 * (3 - gy))) & 0xF;
+        for (int gx = 0; gx < 4; gx++)
+            if ((rown >> gx) & 1) nibs |= 1u << (4 * gx + gy);
+    }
+    int minc = 3, maxc = 0;
+    for (int gx = 0; gx < 4; gx++)
+        if ((nibs >> (4 * gx)) & 0xF) { if (gx < minc) minc = gx; if (gx > maxc) maxc = gx; }
+    return nibs | ((uint32_t)minc << 16) | ((uint32_t)maxc << 18);
+}
+struct ShapeTable { uint32_t s[32]; };
+constexpr ShapeTable make_shape_table() {
+    ShapeTable t{};
+    for (int k = 0; k < 7; k++)
+        for (int r = 0; r < 4; r++) t.s[k * 4 + r] = make_shape(k, r);
+    for (int r = 0; r < 4; r++) t.s[28 + r] = 0;   // kind 7 = "no piece" (gameField.cpp:147-151)
+    return t;
+}
+constexpr ShapeTable SHAPES = make_shape_table();
+
+// ---------------------------------------------------------------- context (read-only per launch)
+struct Ctx {
+    const uint32_t* shapes;          // 32 shape words (LDS on the GPU)
+    const uint8_t* const* chunks;    // RNG table chunks: chunks[c][seed16 * 624 + r]
+    const uint8_t* first_ok;         // [65536]
+    const double* combo_pow;         // [256] pow(c, 1.4 + 0.01 c) from the host libm (Combo.cpp:41)
+    uint32_t n_draws;                // draws available per seed = n_chunks * 624
+    uint32_t margin;                 // ST_NEED_EXTEND when a draw counter comes this close to n_draws
+    int H;
+    uint32_t floor_bits;             // ~0u << H
+};
+
+// ---------------------------------------------------------------- one player-board in registers
+struct Player {
+    uint32_t col[NCOL];
+    int kind, rot, x, y, next;
+    int dead, lock_armed, reward;
+    int inc_count, combo_count, line_count, qlen, q_overflow;
+    int32_t time_ms, drop_delay, drop_time, speedup_time, lock_time;
+    int32_t combo_start, combo_time, min_remaining;
+    uint32_t combo_remaining;
+    float incoming;
+    uint32_t piece_draws, hole_draws;
+    uint32_t lines_sent, lines_cleared, lines_blocked, max_combo, lines_seen, garbage_cleared;
+    int32_t qcount[FIFO_CAP];
+    int32_t qdelay[FIFO_CAP];
+    int q_loaded;                    // FIFO words were read from memory (qlen > 0 at load time)
+};
+
+template <int P>
+struct Game {
+    Player pl[P];
+    uint32_t seed16;                 // low 16 bits of the seed (table row)
+    int round_over, last_winner;
+    uint32_t episode;
+    uint32_t status;                 // te::Status bits raised while stepping this game
+};
+
+// ---------------------------------------------------------------- load / store (SoA, coalesced)
+// state[(w * P + p) * n + slot]; game words at gstate[w * n + slot]
+template <int P>
+TE_HD void load_game(const uint32_t* state, const uint32_t* gstate, size_t n, size_t slot, Game<P>& g) {
+    uint32_t meta = gstate[(size_t)G_META * n + slot];
+    g.seed16 = meta & 0xFFFFu;
+    g.round_over = (meta >> 16) & 1;
+    g.last_winner = (int)((meta >> 17) & 0xF) - 1;
+    g.episode = gstate[(size_t)G_EPISODE * n + slot];
+    g.status = 0;
+    TE_UNROLL
+    for (int p = 0; p < P; p++) {
+        Player& q = g.pl[p];
+        const uint32_t* s = state + (size_t)p * n + slot;
+        const size_t ws = (size_t)P * n;
+        for (int c = 0; c < NCOL; c++) q.col[c] = s[(size_t)(W_COL0 + c) * ws];
+        uint32_t w = s[(size_t)W_PIECE * ws];
+        q.kind = w & 7; q.rot = (w >> 3) & 3; q.x = (int)((w >> 5) & 15) - 4; q.y = (w >> 9) & 31;
+        q.next = (w >> 14) & 7; q.dead = (w >> 17) & 1; q.lock_armed = (w >> 18) & 1; q.reward = (w >> 19) & 255;
+        w = s[(size_t)W_MISC * ws];
+        q.inc_count = w & 255; q.combo_count = (w >> 8) & 255; q.line_count = (w >> 16) & 255;
+        q.qlen = (w >> 24) & 15; q.q_overflow = (w >> 28) & 1;
+        q.time_ms = (int32_t)s[(size_t)W_TIME * ws];
+        w = s[(size_t)W_DROPCOMBO * ws];
+        q.drop_delay = w & 0xFFFF; q.combo_remaining = w >> 16;
+        q.drop_time = (int32_t)s[(size_t)W_DROP_TIME * ws];
+        q.speedup_time = (int32_t)s[(size_t)W_SPEEDUP_TIME * ws];
+        q.lock_time = (int32_t)s[(size_t)W_LOCK_TIME * ws];
+        q.combo_start = (int32_t)s[(size_t)W_COMBO_START * ws];
+        q.combo_time = (int32_t)s[(size_t)W_COMBO_TIME * ws];
+        q.incoming = u2f(s[(size_t)W_INCOMING * ws]);
+        q.min_remaining = (int32_t)s[(size_t)W_MIN_REMAINING * ws];
+        q.piece_draws = s[(size_t)W_PIECE_DRAWS * ws];
+        q.hole_draws = s[(size_t)W_HOLE_DRAWS * ws];
+        w = s[(size_t)W_STATS0 * ws]; q.lines_sent = w & 0xFFFF; q.lines_cleared = w >> 16;
+        w = s[(size_t)W_STATS1 * ws]; q.lines_blocked = w & 0xFFFF; q.max_combo = w >> 16;
+        w = s[(size_t)W_STATS2 * ws]; q.lines_seen = w & 0xFFFF; q.garbage_cleared = w >> 16;
+        q.q_loaded = q.qlen > 0;
+        for (int i = 0; i < FIFO_CAP; i++) { q.qcount[i] = 0; q.qdelay[i] = 0; }
+        if (q.q_loaded) {
+            for (int i = 0; i < FIFO_CAP / 2; i++) {
+                uint32_t cw = s[(size_t)(W_FIFO_COUNT0 + i) * ws];
+                q.qcount[2 * i] = (int16_t)(cw & 0xFFFF);
+                q.qcount[2 * i + 1] = (int16_t)(cw >> 16);
+            }
+            for (int i = 0; i < FIFO_CAP; i++) q.qdelay[i] = (int32_t)s[(size_t)(W_FIFO_DELAY0 + i) * ws];
+        }
+    }
+}
+
+template <int P>
+TE_HD void store_game(uint32_t* state, uint32_t* gstate, size_t n, size_t slot, const Game<P>& g) {
+    gstate[(size_t)G_META * n + slot] = g.seed16 | ((uint32_t)g.round_over << 16) | ((uint32_t)(g.last_winner + 1) << 17);
+    gstate[(size_t)G_EPISODE * n + slot] = g.episode;
+    TE_UNROLL
+    for (int p = 0; p < P; p++) {
+        const Player& q = g.pl[p];
+        uint32_t* s = state + (size_t)p * n + slot;
+        const size_t ws = (size_t)P * n;
+        for (int c = 0; c < NCOL; c++) s[(size_t)(W_COL0 + c) * ws] = q.col[c];
+        s[(size_t)W_PIECE * ws] = (uint32_t)q.kind | ((uint32_t)q.rot << 3) | ((uint32_t)(q.x + 4) << 5) | ((uint32_t)q.y << 9) |
+                                  ((uint32_t)q.next << 14) | ((uint32_t)q.dead << 17) | ((uint32_t)q.lock_armed << 18) |
+                                  ((uint32_t)(q.reward & 255) << 19);
+        s[(size_t)W_MISC * ws] = (uint32_t)(q.inc_count & 255) | ((uint32_t)(q.combo_count & 255) << 8) |
+                                 ((uint32_t)(q.line_count & 255) << 16) | ((uint32_t)q.qlen << 24) | ((uint32_t)q.q_overflow << 28);
+        s[(size_t)W_TIME * ws] = (uint32_t)q.time_ms;
+        s[(size_t)W_DROPCOMBO * ws] = ((uint32_t)q.drop_delay & 0xFFFF) | (q.combo_remaining << 16);
+        s[(size_t)W_DROP_TIME * ws] = (uint32_t)q.drop_time;
+        s[(size_t)W_SPEEDUP_TIME * ws] = (uint32_t)q.speedup_time;
+        s[(size_t)W_LOCK_TIME * ws] = (uint32_t)q.lock_time;
+        s[(size_t)W_COMBO_START * ws] = (uint32_t)q.combo_start;
+        s[(size_t)W_COMBO_TIME * ws] = (uint32_t)q.combo_time;
+        s[(size_t)W_INCOMING * ws] = f2u(q.incoming);
+        s[(size_t)W_MIN_REMAINING * ws] = (uint32_t)q.min_remaining;
+        s[(size_t)W_PIECE_DRAWS * ws] = q.piece_draws;
+        s[(size_t)W_HOLE_DRAWS * ws] = q.hole_draws;
+        s[(size_t)W_STATS0 * ws] = (q.lines_sent & 0xFFFF) | (q.lines_cleared << 16);
+        s[(size_t)W_STATS1 * ws] = (q.lines_blocked & 0xFFFF) | (q.max_combo << 16);
+        s[(size_t)W_STATS2 * ws] = (q.lines_seen & 0xFFFF) | (q.garbage_cleared << 16);
+        if (q.q_loaded || q.qlen > 0) {
+            for (int i = 0; i < FIFO_CAP / 2; i++)
+                s[(size_t)(W_FIFO_COUNT0 + i) * ws] = ((uint32_t)q.qcount[2 * i] & 0xFFFF) | ((uint32_t)q.qcount[2 * i + 1] << 16);
+            for (int i = 0; i < FIFO_CAP; i++) s[(size_t)(W_FIFO_DELAY0 + i) * ws] = (uint32_t)q.qdelay[i];
+        }
+    }
+}
+
+// ---------------------------------------------------------------- board primitives
+
+TE_HD uint32_t shape_of(const Ctx& cx, int kind, int rot) { return cx.shapes[(kind << 2) | rot]; }
+
+// band window B(y): nibble c+2 = rows y..y+3 of column c (floor below H), wall nibbles elsewhere.
+TE_HD uint64_t band_window(const Ctx& cx, const Player& q, int y) {
+    uint32_t lo = 0xFFu, hi = 0xFFFF0000u;
+    for (int c = 0; c < 6; c++) lo |= ((uint32_t)((int32_t)(q.col[c] | cx.floor_bits) >> y) & 0xFu) << (4 * c + 8);
+    for (int c = 6; c < NCOL; c++) hi |= ((uint32_t)((int32_t)(q.col[c] | cx.floor_bits) >> y) & 0xFu) << (4 * (c - 6));
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// gameField.cpp:10-20 BasicField::possible, against a prepared band window
+TE_HD bool fits_band(uint64_t band, uint32_t shape, int x) {
+    unsigned xs = (unsigned)(x + 2);
+    if (xs > 12u) return false;          // x < -2 or x > 10: some occupied piece column is outside the board
+    return (((uint64_t)(shape & 0xFFFFu) << (4 * xs)) & band) == 0;
+}
+
+TE_HD bool fits_at(const Ctx& cx, const Player& q, uint32_t shape, int x, int y) {
+    return fits_band(band_window(cx, q, y), shape, x);
+}
+
+// dynamic column read without dynamic register indexing
+TE_HD uint32_t col_at(const Player& q, int i) {
+    uint32_t a0 = (i & 1) ? q.col[1] : q.col[0];
+    uint32_t a1 = (i & 1) ? q.col[3] : q.col[2];
+    uint32_t a2 = (i & 1) ? q.col[5] : q.col[4];
+    uint32_t a3 = (i & 1) ? q.col[7] : q.col[6];
+    uint32_t a4 = (i & 1) ? q.col[9] : q.col[8];
+    uint32_t b0 = (i & 2) ? a1 : a0;
+    uint32_t b1 = (i & 2) ? a3 : a2;
+    uint32_t d0 = (i & 4) ? b1 : b0;
+    return (i & 8) ? a4 : d0;
+}
+
+// gameField.cpp:49-53 BasicField::hd — closed form: per occupied piece column, the first occupied
+// square (or the floor) strictly below the column's top cell bounds how far its bottom cell can go.
+// Equals the step-by-step loop also when the start position itself overlaps (distance 0).
+TE_HD int drop_distance(const Ctx& cx, const Player& q, uint32_t shape) {
+    int dist = 64;
+    for (int gx = 0; gx < 4; gx++) {
+        uint32_t nib = (shape >> (4 * gx)) & 0xFu;
+        if (nib) {
+            int top = q.y + ctz32(nib);
+            int bottom = q.y + (31 - clz32(nib));
+            uint32_t below = (col_at(q, q.x + gx) | cx.floor_bits) >> (top + 1);
+            int first = below ? ctz32(below) + top + 1 : 32;
+            dist = imin(dist, imax(0, first - bottom - 1));
+        }
+    }
+    return dist == 64 ? 0 : dist;
+}
+
+// gameField.cpp:105-110 addPiece (occupancy only)
+TE_HD void stamp(Player& q, uint32_t shape) {
+    unsigned xs = (unsigned)(q.x + 2);
+    if (xs > 12u) return;
+    uint64_t placed = (uint64_t)(shape & 0xFFFFu) << (4 * xs);
+    for (int c = 0; c < NCOL; c++) q.col[c] |= ((uint32_t)(placed >> (4 * c + 8)) & 0xFu) << q.y;
+}
+
+// gameField.cpp:120-145 clearlines (+ removeline :112-118): rows >= piece.posY that are full are
+// removed bottom-up, everything above shifts down, and a row that shifts into the scanned range is
+// examined too — i.e. "remove the lowest full row in range" until none is left.
+TE_HD int clear_rows(const Ctx& cx, Player& q) {
+    uint32_t range = (~0u << q.y) & ~cx.floor_bits;
+    int cleared = 0;
+    for (;;) {
+        uint32_t full = range;
+        for (int c = 0; c < NCOL; c++) full &= q.col[c];
+        if (!full) break;
+        int r = 31 - clz32(full);
+        uint32_t above = (1u << r) - 1u;            // rows 0..r-1
+        uint32_t keep = ~((above << 1) | 1u);       // rows r+1..
+        for (int c = 0; c < NCOL; c++) q.col[c] = (q.col[c] & keep) | ((q.col[c] & above) << 1);
+        cleared++;
+    }
+    return cleared;
+}
+
+// ---------------------------------------------------------------- RNG table reads
+TE_HD uint32_t table_byte(const Ctx& cx, uint32_t seed16, uint32_t draw, uint32_t& status) {
+    if (draw + cx.margin >= cx.n_draws) {
+        status |= ST_NEED_EXTEND;
+        if (draw >= cx.n_draws) { status |= ST_STREAM_EXHAUSTED; draw = cx.n_draws - 1; }
+    }
+    uint32_t chunk = draw / (uint32_t)CHUNK;
+    uint32_t r = draw - chunk * (uint32_t)CHUNK;
+    return cx.chunks[chunk][(size_t)seed16 * CHUNK + r];
+}
+
+// ---------------------------------------------------------------- garbage queue (Garbage.cpp)
+TE_HD void q_pop_front(Player& q) {
+    for (int i = 0; i + 1 < FIFO_CAP; i++) { q.qcount[i] = q.qcount[i + 1]; q.qdelay[i] = q.qdelay[i + 1]; }
+    q.qcount[FIFO_CAP - 1] = 0; q.qdelay[FIFO_CAP - 1] = 0;
+    q.qlen--;
+}
+
+// Garbage.cpp:22-24 add (initialDelay 1000)
+TE_HD void q_add(Player& q, int amount, int32_t t, uint32_t& status) {
+    if (q.qlen >= FIFO_CAP) { q.q_overflow = 1; status |= ST_FIFO_OVERFLOW; return; }
+    for (int i = 0; i < FIFO_CAP; i++)
+        if (i == q.qlen) { q.qcount[i] = (int16_t)amount; q.qdelay[i] = t + 1000; }
+    q.qlen++;
+}
+
+// Garbage.cpp:26-52 block (freezeDelay 450)
+TE_HD int q_block(Player& q, int amount, int32_t t, bool freeze) {
+    if (q.qlen == 0) return amount;
+    int32_t head_delay = q.qdelay[0];
+    int blocked = 0;
+    while (amount && q.qlen) {
+        // whole head packet at once when it is not larger than what is left to block
+        int take = imin(amount, (int)q.qcount[0]);
+        if (take < 1) take = 1;                       // count <= 0 never occurs; mirror the decrement loop
+        q.qcount[0] -= take; amount -= take; blocked += take;
+        if (q.qcount[0] == 0) q_pop_front(q);
+    }
+    q.lines_blocked = (q.lines_blocked + (uint32_t)blocked) & 0xFFFFu;
+    if (q.qlen) {
+        if (head_delay > q.qdelay[0]) q.qdelay[0] = head_delay;
+        if (freeze) q.qdelay[0] = imin(q.qdelay[0] + 450, t + q.min_remaining + 450);
+    } else
+        q.min_remaining = 1000;
+    return amount;
+}
+
+// Garbage.cpp:54-72 check (addDelay 450, Garbage.cpp:7)
+TE_HD bool q_release(Player& q, int32_t t) {
+    if (q.qlen == 0) return false;
+    if (t > q.qdelay[0]) {
+        int32_t next_delay = q.qdelay[0] + 450;
+        if (--q.qcount[0] == 0) q_pop_front(q);
+        if (q.qlen) {
+            if (next_delay > q.qdelay[0]) q.qdelay[0] = next_delay;
+            q.min_remaining = q.qdelay[0] - t;
+        } else
+            q.min_remaining = 1000;
+        return true;
+    }
+    q.min_remaining = imin(q.min_remaining, q.qdelay[0] - t);
+    return false;
+}
+
+// Garbage.cpp:9-14 count (uint16 sum)
+TE_HD int q_total(const Player& q) {
+    uint32_t total = 0;
+    for (int i = 0; i < FIFO_CAP; i++)
+        if (i < q.qlen) total += (uint32_t)q.qcount[i];
+    return (int)(total & 0xFFFFu);
+}
+
+// ---------------------------------------------------------------- combo (Combo.cpp)
+
+// Combo.cpp:15-30 increase: integer quotients accumulate in a float; the float sum is added to the
+// int32 comboTime in float arithmetic and truncated back.
+TE_HD void combo_gain(Player& q, int32_t t, int amount) {
+    if (q.combo_count == 0) { q.combo_start = t; q.combo_time = 0; }
+    q.combo_count = (q.combo_count + 1) & 255;
+    float line_time = 0.0f;
+    for (int i = 0; i < amount; i++) {
+        q.line_count = (q.line_count + 1) & 255;
+        line_time = line_time + (float)(1000 / imax(1, q.line_count));
+    }
+    float add = (float)(800 / imax(1, q.combo_count)) + line_time;
+    q.combo_time = (int32_t)((float)q.combo_time + add);
+    if ((uint32_t)q.combo_count > q.max_combo) q.max_combo = (uint32_t)q.combo_count;
+}
+
+// Combo.cpp:32-48 check
+TE_HD int combo_expire(const Ctx& cx, Player& q, int32_t t) {
+    int32_t left = q.combo_start + q.combo_time - t;
+    q.combo_remaining = left < 0 ? 0u : ((uint32_t)left & 0xFFFFu);
+    if (t > q.combo_start + q.combo_time && q.combo_count != 0) {
+        float duration = 1.f + (float)t / 60000.f * 0.1f;
+        double v = cx.combo_pow[q.combo_count] * (double)duration;
+        int lines = (int)((uint32_t)(int64_t)v & 0xFFFFu);
+        q.combo_count = 0;
+        q.line_count = 0;
+        return lines;
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------- player logic (gamePlay.cpp)
+
+// gamePlay.cpp:71-88 makeNewPiece / copyPiece; true when the spawn collides (piece stamped, dead)
+TE_HD bool spawn_next(const Ctx& cx, Player& q, uint32_t seed16, uint32_t& status) {
+    q.kind = q.next;
+    q.rot = spawn_rot(q.kind);
+    q.x = (NCOL - 4) / 2;
+    q.y = 0;
+    q.next = (int)(table_byte(cx, seed16, q.piece_draws, status) & 7u);
+    q.piece_draws++;
+    uint32_t shape = shape_of(cx, q.kind, q.rot);
+    if (!fits_at(cx, q, shape, q.x, 0)) { stamp(q, shape); return true; }
+    return false;
+}
+
+// gamePlay.cpp:160-171 sendLines (+ Combo.cpp:50-52 noClear)
+TE_HD int score_clears(Player& q, int cleared) {
+    q.lines_cleared = (q.lines_cleared + (uint32_t)cleared) & 0xFFFFu;
+    if (cleared == 0) { q.combo_time -= 200; return 0; }
+    int amount = q_block(q, cleared - 1, q.time_ms, true);
+    q.lines_sent = (q.lines_sent + (uint32_t)amount) & 0xFFFFu;
+    combo_gain(q, q.time_ms, cleared);
+    return amount;
+}
+
+// gamePlay.cpp:48-52 hd_make (+ DropDelay.cpp:23-26 reset)
+TE_HD void lock_piece(const Ctx& cx, Player& q) {
+    uint32_t shape = shape_of(cx, q.kind, q.rot);
+    q.y += drop_distance(cx, q, shape);
+    stamp(q, shape);
+    q.drop_time = q.time_ms;
+    q.lock_armed = 0;
+}
+
+// gamePlay.cpp:54-59 hd_finish; -1 = died
+TE_HD int settle(const Ctx& cx, Player& q, uint32_t seed16, uint32_t& status) {
+    int sent = score_clears(q, clear_rows(cx, q));
+    if (spawn_next(cx, q, seed16, status)) return -1;
+    return sent;
+}
+
+// gamePlay.cpp:61-69 GamePlay::mDown (+ DropDelay.cpp:23-26 reset, :37-41 set)
+TE_HD bool soft_drop(const Ctx& cx, Player& q) {
+    if (fits_at(cx, q, shape_of(cx, q.kind, q.rot), q.x, q.y + 1)) {
+        q.y++;
+        q.drop_time = q.time_ms;
+        q.lock_armed = 0;
+        return true;
+    }
+    if (!q.lock_armed) q.lock_time = q.time_ms + 400;
+    q.lock_armed = 1;
+    return false;
+}
+
+// DropDelay.cpp:3-21 check
+TE_HD bool gravity_due(Player& q, int32_t t) {
+    if (t - q.speedup_time > 3000) {
+        if (q.drop_delay > 200) q.drop_delay -= 10;
+        else if (q.drop_delay > 100) q.drop_delay -= 5;
+        else if (q.drop_delay > 50) q.drop_delay -= 2;
+        else if (q.drop_delay > 10) q.drop_delay -= 1;
+        q.speedup_time = t;
+    }
+    if (t - q.drop_time > q.drop_delay) { q.drop_time = t; return true; }
+    return false;
+}
+
+// gamePlay.cpp:179-204 pushGarbage / addGarbageLine; true when the piece dies.
+// hole == 10 (float uniform rounding to 1.0) leaves the row without a hole.
+TE_HD bool push_garbage(const Ctx& cx, Player& q, uint32_t seed16, uint32_t& status) {
+    int hole = (int)(table_byte(cx, seed16, q.hole_draws, status) >> 4);
+    q.hole_draws++;
+    uint32_t bottom = 1u << (cx.H - 1);
+    for (int c = 0; c < NCOL; c++) q.col[c] = (q.col[c] >> 1) | (c == hole ? 0u : bottom);
+    if (q.y > 0) q.y--;
+    if (!fits_at(cx, q, shape_of(cx, q.kind, q.rot), q.x, q.y)) {
+        if (q.y > 0) q.y--;
+        else return true;
+    }
+    return false;
+}
+
+// gamePlay.cpp:90-114 delayCheck
+TE_HD int tick(const Ctx& cx, Player& q, int ms, uint32_t seed16, uint32_t& status) {
+    q.time_ms += ms;
+    if (gravity_due(q, q.time_ms)) soft_drop(cx, q);
+    if (q.lock_armed && q.time_ms > q.lock_time && !soft_drop(cx, q)) {    // DropDelay.cpp:43-48
+        lock_piece(cx, q);                                                  // gamePlay.cpp:38-46 hd
+        return settle(cx, q, seed16, status);
+    }
+    int whole = 0;
+    while (q.incoming >= 1.0f) { whole++; q.incoming = q.incoming - 1.f; }
+    if (whole) q_add(q, whole, q.time_ms, status);
+    int sent = combo_expire(cx, q, q.time_ms);
+    if (sent) {
+        sent = q_block(q, sent, q.time_ms, false);
+        q.lines_sent = (q.lines_sent + (uint32_t)sent) & 0xFFFFu;
+    }
+    if (q_release(q, q.time_ms))
+        if (push_garbage(cx, q, seed16, status)) return -1;
+    return sent;
+}
+
+// gamePlay.cpp:206-216 restartRound + :218-230 seed, through the RNG tables (tetris_tables.h).
+// Not reset (as in the reference): reward, inc_count, combo_remaining.
+TE_HD void restart_player(const Ctx& cx, Player& q, uint32_t seed16, uint32_t& status) {
+    for (int c = 0; c < NCOL; c++) q.col[c] = 0;
+    q.qlen = 0; q.q_overflow = 0; q.lines_blocked = 0; q.min_remaining = 1000;
+    for (int i = 0; i < FIFO_CAP; i++) { q.qcount[i] = 0; q.qdelay[i] = 0; }
+    q.combo_start = 0; q.combo_time = 0; q.max_combo = 0; q.combo_count = 0; q.line_count = 0;
+    q.lines_sent = 0; q.lines_cleared = 0; q.garbage_cleared = 0;
+    q.speedup_time = 0; q.drop_delay = 1000; q.drop_time = 0; q.lock_time = 0; q.lock_armed = 0;
+    q.time_ms = 0; q.incoming = 0.0f; q.lines_seen = 0; q.dead = 0;
+    uint32_t j = cx.first_ok[seed16];
+    q.kind = (int)(table_byte(cx, seed16, j, status) & 7u);
+    q.next = (int)(table_byte(cx, seed16, j + 1, status) & 7u);
+    q.rot = spawn_rot(q.kind);
+    q.x = (NCOL - 4) / 2; q.y = 0;
+    q.piece_draws = j + 2; q.hole_draws = 0;
+}
+
+// PythonHandle.cpp:49-71 reset + seed
+template <int P>
+TE_HD void reset_game(const Ctx& cx, Game<P>& g, uint32_t seed16) {
+    g.round_over = 0;
+    int winner = -1, alive = 0;
+    TE_UNROLL
+    for (int p = 0; p < P; p++)
+        if (!g.pl[p].dead) { alive++; winner = p; }
+    g.last_winner = winner;
+    if (P == 1) g.last_winner = 0;
+    if (alive > 1) g.last_winner = -1;
+    g.seed16 = seed16 & 0xFFFFu;
+    TE_UNROLL
+    for (int p = 0; p < P; p++) restart_player(cx, g.pl[p], g.seed16, g.status);
+}
+
+// PythonHandle.cpp:5-25 init: fresh GamePlay objects (nextpiece 0, reward 0, ...), restartRound, seed
+template <int P>
+TE_HD void init_game(const Ctx& cx, Game<P>& g, uint32_t seed16) {
+    TE_UNROLL
+    for (int p = 0; p < P; p++) {
+        Player& q = g.pl[p];
+        q.reward = 0; q.inc_count = 0; q.combo_remaining = 0; q.dead = 0; q.next = 0; q.kind = 7; q.rot = 0;
+        q.q_loaded = 1;
+    }
+    g.episode = 0; g.status = 0;
+    reset_game(cx, g, seed16);
+    g.last_winner = -1;
+}
+
+// ---------------------------------------------------------------- key interpreter
+
+// gameField.cpp:55-103 rcw / rccw / r180 with the 7-offset kick test; turn = +1, +3 (ccw), +2
+TE_HD bool rotate_piece(const Ctx& cx, Player& q, int turn) {
+    int nr = (q.rot + turn) & 3;
+    uint32_t shape = shape_of(cx, q.kind, nr);
+    uint64_t b0 = band_window(cx, q, q.y);
+    if (fits_band(b0, shape, q.x)) { q.rot = nr; return true; }
+    uint64_t b1 = band_window(cx, q, q.y + 1);
+    // (dx,dy) in the reference's order: (0,+1) (-1,0) (+1,0) (-1,+1) (+1,+1) (-2,0) (+2,0)
+    int dx = 99, dy = 0;
+    if (fits_band(b1, shape, q.x)) { dx = 0; dy = 1; }
+    else if (fits_band(b0, shape, q.x - 1)) { dx = -1; }
+    else if (fits_band(b0, shape, q.x + 1)) { dx = 1; }
+    else if (fits_band(b1, shape, q.x - 1)) { dx = -1; dy = 1; }
+    else if (fits_band(b1, shape, q.x + 1)) { dx = 1; dy = 1; }
+    else if (fits_band(b0, shape, q.x - 2)) { dx = -2; }
+    else if (fits_band(b0, shape, q.x + 2)) { dx = 2; }
+    if (dx == 99) return false;
+    q.rot = nr; q.x += dx; q.y += dy;
+    return true;
+}
+
+// PythonHandle.cpp:73-112 action_make
+TE_HD void press_key(const Ctx& cx, Player& q, int key) {
+    if (key >= 1 && key <= 4) {
+        uint32_t shape = shape_of(cx, q.kind, q.rot);
+        uint64_t band = band_window(cx, q, q.y);
+        int dir = (key <= 2) ? -1 : 1;
+        bool repeat = (key == 2 || key == 4);
+        while (fits_band(band, shape, q.x + dir)) { q.x += dir; if (!repeat) break; }
+    } else if (key == 5) {
+        soft_drop(cx, q);
+    } else if (key == 6) {
+        while (soft_drop(cx, q)) {}
+    } else if (key == 7) {
+        lock_piece(cx, q);
+    } else if (key == 8) {
+        rotate_piece(cx, q, 1);
+    } else if (key == 9) {
+        rotate_piece(cx, q, 3);
+    } else if (key == 10) {
+        rotate_piece(cx, q, 2);
+    }
+}
+
+// sventon_utils.py:9-13: [8]*r + [2] + [3]*t + [7], phase-aligned across lanes
+TE_HD void play_rt(const Ctx& cx, Player& q, int r, int t) {
+    for (int i = 0; i < 3; i++)
+        if (i < r) rotate_piece(cx, q, 1);
+    uint32_t shape = shape_of(cx, q.kind, q.rot);
+    uint64_t band = band_window(cx, q, q.y);
+    while (fits_band(band, shape, q.x - 1)) q.x--;
+    for (int i = 0; i < t; i++) {
+        if (!fits_band(band, shape, q.x + 1)) break;   // a blocked single step stays blocked
+        q.x++;
+    }
+    lock_piece(cx, q);
+}
+
+// ---------------------------------------------------------------- the two-phase step
+
+// PythonHandle.cpp:124-136 distributeLines
+template <int P>
+TE_HD void share_lines(Game<P>& g, int sender, int amount) {
+    if (P < 2) return;
+    float each = (float)amount / (float)(P - 1);
+    TE_UNROLL
+    for (int p = 0; p < P; p++)
+        if (p != sender) g.pl[p].incoming = g.pl[p].incoming + each;
+}
+
+// PythonHandle.cpp:149-188 finish_actions (+ action_finish :114-122); returns round_over
+template <int P>
+TE_HD int finish_game(const Ctx& cx, Game<P>& g, int ms) {
+    if (g.round_over) return 1;
+    bool stop = false;
+    TE_UNROLL
+    for (int p = 0; p < P; p++) {
+        Player& q = g.pl[p];
+        if (stop || q.dead) continue;
+        int sent = settle(cx, q, g.seed16, g.status);
+        if (sent == -1) { q.dead = 1; stop = true; continue; }     // the reference breaks out of loop 1
+        if (sent) share_lines<P>(g, p, sent);
+    }
+    int alive = 0;
+    TE_UNROLL
+    for (int p = 0; p < P; p++) {
+        Player& q = g.pl[p];
+        if (q.dead) continue;
+        int sent = tick(cx, q, ms, g.seed16, g.status);
+        if (sent == -1) { q.dead = 1; continue; }
+        if (sent) share_lines<P>(g, p, sent);
+        alive++;
+        q.reward = (int)((q.lines_cleared - q.lines_seen) & 0xFFu);
+        q.lines_seen = q.lines_cleared;
+        q.inc_count = q_total(q) & 255;
+    }
+    if ((P > 1 && alive < 2) || !alive) { g.round_over = 1; return 1; }
+    return 0;
+}
+
+// seed16 = (12345 + 7919 i + 104729 e) mod 65536
+TE_HD uint32_t episode_seed(uint32_t game, uint32_t episode) { return (12345u + 7919u * game + 104729u * episode) & 0xFFFFu; }
+
+// Philox4x32-10 (Salmon et al., SC'11), key (k0, 0), counter (c0, c1, c2, 0): the synthetic policy
+TE_HD void philox4x32_10(uint32_t k0, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t out[4]) {
+    uint32_t k1 = 0u, c3 = 0u;
+    for (int r = 0; r < 10; r++) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+}  // namespace te

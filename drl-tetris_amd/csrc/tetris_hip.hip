@@ -1,0 +1,632 @@
+// libtetris_hip.so — kernels and C ABI of the MI355X batched Tetris environment (gfx950 only).
+//
+// One lane = one game (all its players), state SoA in HBM (tetris_layout.h), step logic in
+// tetris_engine.h.  Launch geometry: 256-thread workgroups (one wave per SIMD of a CU); 64k games
+// = 256 workgroups = one per CU, so the kernel is latency/issue bound, not occupancy bound.
+#include <hip/hip_runtime.h>
+
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "tetris_kernels.h"
+
+using namespace te;
+
+// ============================================================================ device side
+
+__device__ const ShapeTable d_shape_table = make_shape_table();
+
+template <int P, int MODE>
+__global__ __launch_bounds__(256) void k_game(KArgs a) {
+    __shared__ uint32_t s_shapes[32];
+    if (threadIdx.x < 32) s_shapes[threadIdx.x] = d_shape_table.s[threadIdx.x];
+    __syncthreads();
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    LaneCounters cnt = {0, 0, 0, 0};
+    if (i < a.n) game_body<P, MODE>(a, i, s_shapes, cnt);
+    if (MODE == M_ROLLOUT) {
+        // wave reduction, then one atomic per wave and counter
+        for (int off = 32; off > 0; off >>= 1) {
+            cnt.steps += __shfl_down(cnt.steps, off);
+            cnt.episodes += __shfl_down(cnt.episodes, off);
+            cnt.lines += __shfl_down(cnt.lines, off);
+            cnt.sent += __shfl_down(cnt.sent, off);
+        }
+        if ((threadIdx.x & 63) == 0) {
+            if (cnt.steps) atomicAdd(&a.counters[0], cnt.steps);
+            if (cnt.episodes) atomicAdd(&a.counters[1], cnt.episodes);
+            if (cnt.lines) atomicAdd(&a.counters[2], cnt.lines);
+            if (cnt.sent) atomicAdd(&a.counters[3], cnt.sent);
+        }
+    }
+}
+
+// ---- RNG tables: one lane per 16-bit seed, MT state strided [word][seed] (coalesced)
+__global__ __launch_bounds__(256) void k_gen_seed(uint32_t* mt) {
+    uint32_t seed = blockIdx.x * blockDim.x + threadIdx.x;
+    if (seed >= 65536u) return;
+    // randomizer.cpp:34-36,47-49: `short` seed converted to the engine's result type
+    mt_seed(mt + seed, 65536, (uint32_t)(int32_t)(int16_t)(uint16_t)seed);
+}
+
+struct MapArg { uint8_t m[8]; };
+
+__global__ __launch_bounds__(256) void k_gen_chunk(uint32_t* mt, float* w, uint8_t* out, uint8_t* first_ok, int chunk,
+                                                   MapArg map, int only_sz) {
+    uint32_t seed = blockIdx.x * blockDim.x + threadIdx.x;
+    if (seed >= 65536u) return;
+    uint8_t fo = 0;
+    gen_chunk_for_seed(mt + seed, 65536, w + seed, 65536, out + (size_t)seed * CHUNK, &fo, chunk, map.m, only_sz != 0);
+    if (chunk == 0) first_ok[seed] = fo;
+}
+
+template <int P>
+__global__ __launch_bounds__(256) void k_observe(const uint32_t* state, const uint32_t* gstate, int n_games, int n,
+                                                 const int32_t* idx, int H, tetris_record* rec, uint8_t* round_over,
+                                                 int8_t* last_winner) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) observe_body<P>(state, gstate, n_games, i, idx, H, d_shape_table.s, rec, round_over, last_winner);
+}
+
+__global__ __launch_bounds__(256) void k_snapshot(uint32_t* state, uint32_t* gstate, int n_games, int n, const int32_t* idx,
+                                                  int P, uint32_t* blob, int restore) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < (size_t)n * (NGWORDS + P * NWORDS)) snapshot_body(state, gstate, n_games, t, idx, P, blob, restore);
+}
+
+__global__ __launch_bounds__(256) void k_set_dead(uint32_t* state, int n_games, int n, const int32_t* idx, int P,
+                                                  const uint8_t* dead /*[n][P]*/) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n * P) set_dead_body(state, n_games, t, idx, P, dead);
+}
+
+// ============================================================================ host side
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+#define HIP_TRY(expr)                                                                                            \
+    do {                                                                                                         \
+        hipError_t e_ = (expr);                                                                                  \
+        if (e_ != hipSuccess)                                                                                    \
+            return fail(TETRIS_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                        \
+    } while (0)
+
+// RNG tables, shared by every batch on the same device with the same piece map
+struct Tables {
+    int device = -1;
+    uint8_t map[8] = {0};
+    int only_sz = 0;
+    int refs = 0;
+    uint32_t* d_mt = nullptr;        // [624][65536]
+    float* d_w = nullptr;            // [7][65536]
+    uint8_t* d_first_ok = nullptr;   // [65536]
+    double* d_pow = nullptr;         // [256]
+    std::vector<uint8_t*> chunks;    // device pointers, 65536*624 bytes each
+    const uint8_t** d_chunks = nullptr;   // device array [MAX_CHUNKS]
+};
+static std::mutex g_tab_mutex;
+static std::vector<Tables*> g_tables;
+
+static int tables_extend(Tables* t, hipStream_t stream) {
+    if ((int)t->chunks.size() >= MAX_CHUNKS) return fail(TETRIS_E_STREAM, "RNG tables: MAX_CHUNKS reached");
+    uint8_t* d = nullptr;
+    HIP_TRY(hipMalloc((void**)&d, (size_t)65536 * CHUNK));
+    MapArg m;
+    memcpy(m.m, t->map, 8);
+    int c = (int)t->chunks.size();
+    hipLaunchKernelGGL(k_gen_chunk, dim3(256), dim3(256), 0, stream, t->d_mt, t->d_w, d, t->d_first_ok, c, m, t->only_sz);
+    HIP_TRY(hipGetLastError());
+    t->chunks.push_back(d);
+    HIP_TRY(hipMemcpyAsync((void*)(t->d_chunks + c), &t->chunks[c], sizeof(uint8_t*), hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    return TETRIS_OK;
+}
+
+static int tables_acquire(Tables** out, int device, const uint8_t map[7], hipStream_t stream) {
+    std::lock_guard<std::mutex> lock(g_tab_mutex);
+    for (Tables* t : g_tables)
+        if (t->device == device && memcmp(t->map, map, 7) == 0) { t->refs++; *out = t; return TETRIS_OK; }
+    Tables* t = new (std::nothrow) Tables();
+    if (!t) return fail(TETRIS_E_HIP, "out of host memory");
+    t->device = device;
+    memcpy(t->map, map, 7);
+    t->only_sz = 1;                                             // PythonHandle.h:116-121 set_pieces
+    for (int i = 0; i < 7; i++) if (map[i] != 2 && map[i] != 3) t->only_sz = 0;
+    HIP_TRY(hipMalloc((void**)&t->d_mt, (size_t)624 * 65536 * 4));
+    HIP_TRY(hipMalloc((void**)&t->d_w, (size_t)7 * 65536 * 4));
+    HIP_TRY(hipMalloc((void**)&t->d_first_ok, 65536));
+    HIP_TRY(hipMalloc((void**)&t->d_pow, 256 * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&t->d_chunks, MAX_CHUNKS * sizeof(uint8_t*)));
+    HIP_TRY(hipMemsetAsync((void*)t->d_chunks, 0, MAX_CHUNKS * sizeof(uint8_t*), stream));
+    double powtab[256];
+    for (int c = 0; c < 256; c++) powtab[c] = pow((double)c, 1.4 + (double)c * 0.01);   // Combo.cpp:41, host libm
+    HIP_TRY(hipMemcpyAsync(t->d_pow, powtab, sizeof powtab, hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(k_gen_seed, dim3(256), dim3(256), 0, stream, t->d_mt);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(stream));
+    for (int c = 0; c < 2; c++) {
+        int rc = tables_extend(t, stream);
+        if (rc) return rc;
+    }
+    t->refs = 1;
+    g_tables.push_back(t);
+    *out = t;
+    return TETRIS_OK;
+}
+
+static void tables_release(Tables* t) {
+    std::lock_guard<std::mutex> lock(g_tab_mutex);
+    if (--t->refs > 0) return;
+    for (size_t i = 0; i < g_tables.size(); i++)
+        if (g_tables[i] == t) { g_tables.erase(g_tables.begin() + i); break; }
+    (void)hipFree(t->d_mt); (void)hipFree(t->d_w); (void)hipFree(t->d_first_ok); (void)hipFree(t->d_pow);
+    for (uint8_t* c : t->chunks) (void)hipFree(c);
+    (void)hipFree((void*)t->d_chunks);
+    delete t;
+}
+
+// grow-on-demand device + pinned-host staging pair
+struct Stage {
+    void* h = nullptr;
+    void* d = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return TETRIS_OK;
+        size_t want = bytes < 4096 ? 4096 : bytes + bytes / 2;
+        if (h) (void)hipHostFree(h);
+        if (d) (void)hipFree(d);
+        h = d = nullptr; cap = 0;
+        HIP_TRY(hipHostMalloc(&h, want, hipHostMallocDefault));
+        HIP_TRY(hipMalloc(&d, want));
+        cap = want;
+        return TETRIS_OK;
+    }
+    void release() {
+        if (h) (void)hipHostFree(h);
+        if (d) (void)hipFree(d);
+        h = d = nullptr; cap = 0;
+    }
+};
+
+struct tetris_batch {
+    int device = 0, N = 0, P = 0, H = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    uint32_t* d_state = nullptr;
+    uint32_t* d_gstate = nullptr;
+    uint32_t* d_status = nullptr;        // [0] sticky te::Status bits
+    unsigned long long* d_counters = nullptr;
+    uint32_t* h_status = nullptr;        // pinned
+    Tables* tab = nullptr;
+    uint32_t margin = 64;
+    uint32_t game_offset = 0;
+    Stage s_idx, s_in0, s_in1, s_in2, s_out0, s_out1, s_out2, s_big;
+};
+
+static KArgs base_args(tetris_batch* b, int n, const int32_t* d_idx) {
+    KArgs a;
+    memset(&a, 0, sizeof a);
+    a.state = b->d_state; a.gstate = b->d_gstate; a.status = b->d_status;
+    a.chunks = (const uint8_t* const*)b->tab->d_chunks; a.first_ok = b->tab->d_first_ok; a.combo_pow = b->tab->d_pow;
+    a.n_draws = (uint32_t)b->tab->chunks.size() * CHUNK; a.margin = b->margin;
+    a.H = b->H; a.n_games = b->N; a.n = n; a.idx = d_idx; a.game_offset = b->game_offset;
+    return a;
+}
+
+template <int MODE>
+static int launch_game(tetris_batch* b, const KArgs& a) {
+    dim3 grid((unsigned)((a.n + 255) / 256)), block(256);
+    if (b->P == 1) hipLaunchKernelGGL((k_game<1, MODE>), grid, block, 0, b->stream, a);
+    else hipLaunchKernelGGL((k_game<2, MODE>), grid, block, 0, b->stream, a);
+    HIP_TRY(hipGetLastError());
+    return TETRIS_OK;
+}
+
+// drain + read the sticky status word; extend the RNG tables when a board came close to their end
+static int finish_call(tetris_batch* b) {
+    HIP_TRY(hipMemcpyAsync(b->h_status, b->d_status, 4, hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    uint32_t st = *b->h_status;
+    if (st & ST_STREAM_EXHAUSTED) return fail(TETRIS_E_STREAM, "an episode ran past the RNG tables; state is invalid");
+    if (st & ST_FIFO_OVERFLOW) return fail(TETRIS_E_FIFO, "garbage FIFO overflow (> 8 pending packets); state is invalid");
+    if (st & ST_NEED_EXTEND) {
+        std::lock_guard<std::mutex> lock(g_tab_mutex);
+        int rc = tables_extend(b->tab, b->stream);
+        if (rc) return rc;
+        HIP_TRY(hipMemsetAsync(b->d_status, 0, 4, b->stream));
+        HIP_TRY(hipStreamSynchronize(b->stream));
+    }
+    return TETRIS_OK;
+}
+
+static int check_batch(tetris_batch* b) {
+    if (!b) return fail(TETRIS_E_ARG, "null batch");
+    HIP_TRY(hipSetDevice(b->device));
+    return TETRIS_OK;
+}
+
+// copies idx to the device (or returns NULL for identity); validates range
+static int stage_idx(tetris_batch* b, const int32_t* idx, int n, const int32_t** d_idx) {
+    *d_idx = nullptr;
+    if (n < 0 || (!idx && n > b->N)) return fail(TETRIS_E_ARG, "n out of range");
+    if (!idx) return TETRIS_OK;
+    for (int i = 0; i < n; i++)
+        if (idx[i] < 0 || idx[i] >= b->N) return fail(TETRIS_E_ARG, "game index out of range");
+    int rc = b->s_idx.ensure((size_t)n * 4 + 4);
+    if (rc) return rc;
+    memcpy(b->s_idx.h, idx, (size_t)n * 4);
+    HIP_TRY(hipMemcpyAsync(b->s_idx.d, b->s_idx.h, (size_t)n * 4, hipMemcpyHostToDevice, b->stream));
+    *d_idx = (const int32_t*)b->s_idx.d;
+    return TETRIS_OK;
+}
+
+static int stage_in(tetris_batch* b, Stage& s, const void* src, size_t bytes) {
+    int rc = s.ensure(bytes + 4);
+    if (rc) return rc;
+    memcpy(s.h, src, bytes);
+    HIP_TRY(hipMemcpyAsync(s.d, s.h, bytes, hipMemcpyHostToDevice, b->stream));
+    return TETRIS_OK;
+}
+
+extern "C" {
+
+const char* tetris_last_error(void) { return g_err.c_str(); }
+
+int tetris_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return fail(TETRIS_E_HIP, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+    return n;
+}
+
+int tetris_record_size(void) { return (int)sizeof(tetris_record); }
+int tetris_layout_words(void) { return NWORDS; }
+int tetris_snapshot_words(const tetris_batch* b) { return b ? NGWORDS + b->P * NWORDS : 0; }
+int tetris_table_chunks(const tetris_batch* b) { return b && b->tab ? (int)b->tab->chunks.size() : 0; }
+void* tetris_device_state(tetris_batch* b) { return b ? b->d_state : nullptr; }
+void* tetris_stream(tetris_batch* b) { return b ? (void*)b->stream : nullptr; }
+
+int tetris_destroy(tetris_batch* b) {
+    if (!b) return TETRIS_OK;
+    (void)hipSetDevice(b->device);
+    if (b->stream) (void)hipStreamSynchronize(b->stream);
+    if (b->tab) tables_release(b->tab);
+    (void)hipFree(b->d_state); (void)hipFree(b->d_gstate); (void)hipFree(b->d_status); (void)hipFree(b->d_counters);
+    if (b->h_status) (void)hipHostFree(b->h_status);
+    Stage* all[] = {&b->s_idx, &b->s_in0, &b->s_in1, &b->s_in2, &b->s_out0, &b->s_out1, &b->s_out2, &b->s_big};
+    for (Stage* s : all) s->release();
+    if (b->ev0) (void)hipEventDestroy(b->ev0);
+    if (b->ev1) (void)hipEventDestroy(b->ev1);
+    if (b->stream) (void)hipStreamDestroy(b->stream);
+    delete b;
+    return TETRIS_OK;
+}
+
+int tetris_create(tetris_batch** out, int n_games, int n_players, int height, int width, const uint8_t piece_map[7],
+                  int device, const int16_t* seeds) {
+    if (!out) return fail(TETRIS_E_ARG, "out is NULL");
+    *out = nullptr;
+    if (n_games < 1) return fail(TETRIS_E_ARG, "n_games must be >= 1");
+    if (n_players != 1 && n_players != 2) return fail(TETRIS_E_ARG, "n_players must be 1 or 2");
+    if (height < 4 || height > MAX_H) return fail(TETRIS_E_ARG, "height must be in [4, 31]");
+    if (width != NCOL) return fail(TETRIS_E_ARG, "width must be 10 (the reference hard-codes 10, gamePlay.cpp:202)");
+    if (!piece_map) return fail(TETRIS_E_ARG, "piece_map is NULL");
+    for (int i = 0; i < 7; i++)
+        if (piece_map[i] > 6) return fail(TETRIS_E_ARG, "piece_map entries must be 0..6");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev < 1)
+        return fail(TETRIS_E_HIP, std::string("no HIP device available (this library has no CPU path): ") +
+                                      (e != hipSuccess ? hipGetErrorString(e) : "device count 0"));
+    if (device < 0 || device >= ndev) return fail(TETRIS_E_ARG, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+    tetris_batch* b = new (std::nothrow) tetris_batch();
+    if (!b) return fail(TETRIS_E_HIP, "out of host memory");
+    b->device = device; b->N = n_games; b->P = n_players; b->H = height;
+#define CREATE_TRY(expr)                                                                    \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess) {                                                             \
+            tetris_destroy(b);                                                              \
+            return fail(TETRIS_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));   \
+        }                                                                                   \
+    } while (0)
+    CREATE_TRY(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+    CREATE_TRY(hipEventCreate(&b->ev0));
+    CREATE_TRY(hipEventCreate(&b->ev1));
+    CREATE_TRY(hipMalloc((void**)&b->d_state, (size_t)NWORDS * n_players * n_games * 4));
+    CREATE_TRY(hipMalloc((void**)&b->d_gstate, (size_t)NGWORDS * n_games * 4));
+    CREATE_TRY(hipMalloc((void**)&b->d_status, 16));
+    CREATE_TRY(hipMalloc((void**)&b->d_counters, 4 * sizeof(unsigned long long)));
+    CREATE_TRY(hipHostMalloc((void**)&b->h_status, 64, hipHostMallocDefault));
+    CREATE_TRY(hipMemsetAsync(b->d_status, 0, 16, b->stream));
+    CREATE_TRY(hipMemsetAsync(b->d_state, 0, (size_t)NWORDS * n_players * n_games * 4, b->stream));
+    int rc = tables_acquire(&b->tab, device, piece_map, b->stream);
+    if (rc) { std::string keep = g_err; tetris_destroy(b); return fail(rc, keep); }
+    const int16_t* d_seeds = nullptr;
+    if (seeds) {
+        rc = stage_in(b, b->s_in0, seeds, (size_t)n_games * 2);
+        if (rc) { std::string keep = g_err; tetris_destroy(b); return fail(rc, keep); }
+        d_seeds = (const int16_t*)b->s_in0.d;
+    }
+    KArgs a = base_args(b, n_games, nullptr);
+    a.seeds = d_seeds;
+    rc = launch_game<M_INIT>(b, a);
+    if (!rc) rc = finish_call(b);
+    if (rc) { std::string keep = g_err; tetris_destroy(b); return fail(rc, keep); }
+    *out = b;
+    return TETRIS_OK;
+}
+
+int tetris_set_game_offset(tetris_batch* b, uint64_t first_game_id) {
+    if (!b) return fail(TETRIS_E_ARG, "null batch");
+    b->game_offset = (uint32_t)first_game_id;
+    return TETRIS_OK;
+}
+
+int tetris_sync(tetris_batch* b) {
+    int rc = check_batch(b);
+    if (rc) return rc;
+    return finish_call(b);
+}
+
+int tetris_reset(tetris_batch* b, const int32_t* idx, int n, const int16_t* seeds) {
+    int rc = check_batch(b);
+    if (rc) return rc;
+    const int32_t* d_idx;
+    if ((rc = stage_idx(b, idx, n, &d_idx))) return rc;
+    if (n == 0) return TETRIS_OK;
+    KArgs a = base_args(b, n, d_idx);
+    if (seeds) {
+        if ((rc = stage_in(b, b->s_in0, seeds, (size_t)n * 2))) return rc;
+        a.seeds = (const int16_t*)b->s_in0.d;
+    }
+    if ((rc = launch_game<M_RESET>(b, a))) return rc;
+    return finish_call(b);
+}
+
+// host keys [n][P][K] -> device [K][P][n]; host lens [n][P] -> device [P][n]
+static int stage_keys(tetris_batch* b, int n, const uint8_t* keys, const uint8_t* lens, int max_keys, KArgs& a) {
+    if (!keys || !lens || max_keys < 1) return fail(TETRIS_E_ARG, "keys/lens/max_keys");
+    const int P = b->P;
+    int rc = b->s_in0.ensure((size_t)n * P * max_keys + 4);
+    if (rc) return rc;
+    if ((rc = b->s_in1.ensure((size_t)n * P + 4))) return rc;
+    uint8_t* hk = (uint8_t*)b->s_in0.h;
+    uint8_t* hl = (uint8_t*)b->s_in1.h;
+    for (int i = 0; i < n; i++)
+        for (int p = 0; p < P; p++) {
+            int len = lens[(size_t)i * P + p];
+            if (len > max_keys) return fail(TETRIS_E_ARG, "lens[i][p] > max_keys");
+            hl[(size_t)p * n + i] = (uint8_t)len;
+            for (int k = 0; k < max_keys; k++)
+                hk[((size_t)k * P + p) * n + i] = keys[((size_t)i * P + p) * max_keys + k];
+        }
+    HIP_TRY(hipMemcpyAsync(b->s_in0.d, hk, (size_t)n * P * max_keys, hipMemcpyHostToDevice, b->stream));
+    HIP_TRY(hipMemcpyAsync(b->s_in1.d, hl, (size_t)n * P, hipMemcpyHostToDevice, b->stream));
+    a.keys = (const uint8_t*)b->s_in0.d; a.lens = (const uint8_t*)b->s_in1.d; a.max_keys = max_keys;
+    return TETRIS_OK;
+}
+
+static int stage_outputs(tetris_batch* b, int n, KArgs& a) {
+    int rc;
+    if ((rc = b->s_out0.ensure((size_t)n + 4))) return rc;
+    if ((rc = b->s_out1.ensure((size_t)n * b->P + 4))) return rc;
+    if ((rc = b->s_out2.ensure((size_t)n * b->P + 4))) return rc;
+    a.done = (uint8_t*)b->s_out0.d; a.lines = (uint8_t*)b->s_out1.d; a.dead = (uint8_t*)b->s_out2.d;
+    return TETRIS_OK;
+}
+
+// device [P][n] -> host [n][P]
+static int fetch_outputs(tetris_batch* b, int n, uint8_t* done, uint8_t* lines, uint8_t* dead) {
+    const int P = b->P;
+    HIP_TRY(hipMemcpyAsync(b->s_out0.h, b->s_out0.d, (size_t)n, hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipMemcpyAsync(b->s_out1.h, b->s_out1.d, (size_t)n * P, hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipMemcpyAsync(b->s_out2.h, b->s_out2.d, (size_t)n * P, hipMemcpyDeviceToHost, b->stream));
+    int rc = finish_call(b);
+    if (rc) return rc;
+    if (done) memcpy(done, b->s_out0.h, (size_t)n);
+    const uint8_t* hl = (const uint8_t*)b->s_out1.h;
+    const uint8_t* hd = (const uint8_t*)b->s_out2.h;
+    for (int i = 0; i < n; i++)
+        for (int p = 0; p < P; p++) {
+            if (lines) lines[(size_t)i * P + p] = hl[(size_t)p * n + i];
+            if (dead) dead[(size_t)i * P + p] = hd[(size_t)p * n + i];
+        }
+    return TETRIS_OK;
+}
+
+int tetris_make_actions(tetris_batch* b, const int32_t* idx, int n, const uint8_t* keys, const uint8_t* lens, int max_keys) {
+    int rc = check_batch(b);
+    if (rc) return rc;
+    const int32_t* d_idx;
+    if ((rc = stage_idx(b, idx, n, &d_idx))) return rc;
+    if (n == 0) return TETRIS_OK;
+    KArgs a = base_args(b, n, d_idx);
+    if ((rc = stage_keys(b, n, keys, lens, max_keys, a))) return rc;
+    if ((rc = launch_game<M_MAKE>(b, a))) return rc;
+    return finish_call(b);
+}
+
+int tetris_finish_actions(tetris_batch* b, const int32_t* idx, int n, int ms, uint8_t* done, uint8_t* lines, uint8_t* dead) {
+    int rc = check_batch(b);
+    if (rc) return rc;
+    const int32_t* d_idx;
+    if ((rc = stage_idx(b, idx, n, &d_idx))) return rc;
+    if (n == 0) return TETRIS_OK;
+    KArgs a = base_args(b, n, d_idx);
+    a.ms = ms;
+    if ((rc = stage_outputs(b, n, a))) return rc;
+    if ((rc = launch_game<M_FINISH>(b, a))) return rc;
+    return fetch_outputs(b, n, done, lines, dead);
+}
+
+int tetris_step_keys(tetris_batch* b, const int32_t* idx, int n, const uint8_t* keys, const uint8_t* lens, int max_keys,
+                     int ms, uint8_t* done, uint8_t* lines, uint8_t* dead) {
+    int rc = check_batch(b);
+    if (rc) return rc;
+    const int32_t* d_idx;
+    if ((rc = stage_idx(b, idx, n, &d_idx))) return rc;
+    if (n == 0) return TETRIS_OK;
+    KArgs a = base_args(b, n, d_idx);
+    a.ms = ms;
+    if ((rc = stage_keys(b, n, keys, lens, max_keys, a))) return rc;
+    if ((rc = stage_outputs(b, n, a))) return rc;
+    if ((rc = launch_game<M_STEP_KEYS>(b, a))) return rc;
+    return fetch_outputs(b, n, done, lines, dead);
+}
+
+int tetris_step_rt_dev(tetris_batch* b, const uint8_t* d_rot, const uint8_t* d_trans, const uint8_t* d_player, int ms,
+                       uint8_t* d_done, uint8_t* d_lines, uint8_t* d_dead) {
+    int rc = check_batch(b);
+    if (rc) return rc;
+    if (!d_rot || !d_trans) return fail(TETRIS_E_ARG, "rot/trans are NULL");
+    KArgs a = base_args(b, b->N, nullptr);
+    a.rot = d_rot; a.trans = d_trans; a.player = d_player; a.ms = ms;
+    a.done = d_done; a.lines = d_lines; a.dead = d_dead;
+    return launch_game<M_STEP_RT>(b, a);
+}
+
+int tetris_step_rt(tetris_batch* b, const uint8_t* rot, const uint8_t* trans, const uint8_t* player, int ms, uint8_t* done,
+                   uint8_t* lines, uint8_t* dead) {
+    int rc = check_batch(b);
+    if (rc) return rc;
+    if (!rot || !trans) return fail(TETRIS_E_ARG, "rot/trans are NULL");
+    const int n = b->N;
+    if (player)
+        for (int i = 0; i < n; i++)
+            if (player[i] >= b->P) return fail(TETRIS_E_ARG, "player index out of range");
+    KArgs a = base_args(b, n, nullptr);
+    a.ms = ms;
+    if ((rc = stage_in(b, b->s_in0, rot, (size_t)n))) return rc;
+    if ((rc = stage_in(b, b->s_in1, trans, (size_t)n))) return rc;
+    a.rot = (const uint8_t*)b->s_in0.d; a.trans = (const uint8_t*)b->s_in1.d;
+    if (player) {
+        if ((rc = stage_in(b, b->s_in2, player, (size_t)n))) return rc;
+        a.player = (const uint8_t*)b->s_in2.d;
+    }
+    if ((rc = stage_outputs(b, n, a))) return rc;
+    if ((rc = launch_game<M_STEP_RT>(b, a))) return rc;
+    return fetch_outputs(b, n, done, lines, dead);
+}
+
+int tetris_observe_records(tetris_batch* b, const int32_t* idx, int n, tetris_record* records, uint8_t* round_over,
+                           int8_t* last_winner) {
+    int rc = check_batch(b);
+    if (rc) return rc;
+    const int32_t* d_idx;
+    if ((rc = stage_idx(b, idx, n, &d_idx))) return rc;
+    if (n == 0) return TETRIS_OK;
+    const size_t rec_bytes = (size_t)n * b->P * sizeof(tetris_record);
+    if ((rc = b->s_big.ensure(rec_bytes + 16))) return rc;
+    if ((rc = b->s_out0.ensure((size_t)n + 4))) return rc;
+    if ((rc = b->s_out1.ensure((size_t)n + 4))) return rc;
+    dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    tetris_record* d_rec = (tetris_record*)b->s_big.d;
+    if (b->P == 1)
+        hipLaunchKernelGGL(k_observe<1>, grid, block, 0, b->stream, b->d_state, b->d_gstate, b->N, n, d_idx, b->H, d_rec,
+                           (uint8_t*)b->s_out0.d, (int8_t*)b->s_out1.d);
+    else
+        hipLaunchKernelGGL(k_observe<2>, grid, block, 0, b->stream, b->d_state, b->d_gstate, b->N, n, d_idx, b->H, d_rec,
+                           (uint8_t*)b->s_out0.d, (int8_t*)b->s_out1.d);
+    HIP_TRY(hipGetLastError());
+    if (records) HIP_TRY(hipMemcpyAsync(b->s_big.h, b->s_big.d, rec_bytes, hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipMemcpyAsync(b->s_out0.h, b->s_out0.d, (size_t)n, hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipMemcpyAsync(b->s_out1.h, b->s_out1.d, (size_t)n, hipMemcpyDeviceToHost, b->stream));
+    if ((rc = finish_call(b))) return rc;
+    if (records) memcpy(records, b->s_big.h, rec_bytes);
+    if (round_over) memcpy(round_over, b->s_out0.h, (size_t)n);
+    if (last_winner) memcpy(last_winner, b->s_out1.h, (size_t)n);
+    return TETRIS_OK;
+}
+
+static int snapshot_impl(tetris_batch* b, const int32_t* idx, int n, uint32_t* blob, int restore) {
+    int rc = check_batch(b);
+    if (rc) return rc;
+    if (!blob) return fail(TETRIS_E_ARG, "blob is NULL");
+    const int32_t* d_idx;
+    if ((rc = stage_idx(b, idx, n, &d_idx))) return rc;
+    if (n == 0) return TETRIS_OK;
+    const int words = NGWORDS + b->P * NWORDS;
+    const size_t bytes = (size_t)n * words * 4;
+    if ((rc = b->s_big.ensure(bytes + 16))) return rc;
+    if (restore) {
+        memcpy(b->s_big.h, blob, bytes);
+        HIP_TRY(hipMemcpyAsync(b->s_big.d, b->s_big.h, bytes, hipMemcpyHostToDevice, b->stream));
+    }
+    size_t total = (size_t)n * words;
+    hipLaunchKernelGGL(k_snapshot, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, b->stream, b->d_state, b->d_gstate,
+                       b->N, n, d_idx, b->P, (uint32_t*)b->s_big.d, restore);
+    HIP_TRY(hipGetLastError());
+    if (!restore) HIP_TRY(hipMemcpyAsync(b->s_big.h, b->s_big.d, bytes, hipMemcpyDeviceToHost, b->stream));
+    if ((rc = finish_call(b))) return rc;
+    if (!restore) memcpy(blob, b->s_big.h, bytes);
+    return TETRIS_OK;
+}
+
+int tetris_snapshot(tetris_batch* b, const int32_t* idx, int n, uint32_t* blob) { return snapshot_impl(b, idx, n, blob, 0); }
+int tetris_restore(tetris_batch* b, const int32_t* idx, int n, const uint32_t* blob) {
+    return snapshot_impl(b, idx, n, (uint32_t*)blob, 1);
+}
+
+int tetris_set_dead(tetris_batch* b, const int32_t* idx, int n, const uint8_t* dead) {
+    int rc = check_batch(b);
+    if (rc) return rc;
+    if (!dead) return fail(TETRIS_E_ARG, "dead is NULL");
+    const int32_t* d_idx;
+    if ((rc = stage_idx(b, idx, n, &d_idx))) return rc;
+    if (n == 0) return TETRIS_OK;
+    if ((rc = stage_in(b, b->s_in0, dead, (size_t)n * b->P))) return rc;
+    hipLaunchKernelGGL(k_set_dead, dim3((unsigned)((n * b->P + 255) / 256)), dim3(256), 0, b->stream, b->d_state, b->N, n,
+                       d_idx, b->P, (const uint8_t*)b->s_in0.d);
+    HIP_TRY(hipGetLastError());
+    return finish_call(b);
+}
+
+int tetris_rollout_random(tetris_batch* b, int launches, int steps_per_launch, uint32_t policy_seed, uint64_t first_step,
+                          int ms, uint64_t counters[4], float* elapsed_ms) {
+    int rc = check_batch(b);
+    if (rc) return rc;
+    if (launches < 1 || steps_per_launch < 1) return fail(TETRIS_E_ARG, "launches/steps_per_launch must be >= 1");
+    // A launch may consume 2 piece draws per step and player, and the host only looks at the status
+    // word between groups of launches: keep each group <= 256 env-steps and the low-water margin
+    // above what one group can consume, so the tables are always extended in time.
+    if (steps_per_launch > 256) return fail(TETRIS_E_ARG, "steps_per_launch must be <= 256");
+    const int group = 256 / steps_per_launch;
+    const uint32_t saved_margin = b->margin;
+    b->margin = (uint32_t)(2 * group * steps_per_launch + 16);
+    if (b->margin < saved_margin) b->margin = saved_margin;
+    HIP_TRY(hipMemsetAsync(b->d_counters, 0, 4 * sizeof(unsigned long long), b->stream));
+    HIP_TRY(hipEventRecord(b->ev0, b->stream));
+    for (int l = 0; l < launches; l++) {
+        KArgs a = base_args(b, b->N, nullptr);
+        a.ms = ms; a.steps = steps_per_launch; a.policy_seed = policy_seed;
+        a.first_step = first_step + (uint64_t)l * (uint64_t)steps_per_launch;
+        a.counters = b->d_counters;
+        if ((rc = launch_game<M_ROLLOUT>(b, a))) { b->margin = saved_margin; return rc; }
+        if ((l + 1) % group == 0 && l + 1 < launches)
+            if ((rc = finish_call(b))) { b->margin = saved_margin; return rc; }
+    }
+    HIP_TRY(hipEventRecord(b->ev1, b->stream));
+    unsigned long long host_counters[4];
+    HIP_TRY(hipMemcpyAsync(b->h_status + 2, b->d_counters, sizeof host_counters, hipMemcpyDeviceToHost, b->stream));
+    rc = finish_call(b);
+    b->margin = saved_margin;
+    if (rc) return rc;
+    memcpy(host_counters, b->h_status + 2, sizeof host_counters);
+    if (counters)
+        for (int k = 0; k < 4; k++) counters[k] += host_counters[k];
+    if (elapsed_ms) HIP_TRY(hipEventElapsedTime(elapsed_ms, b->ev0, b->ev1));
+    return TETRIS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,233 @@
+// Kernel bodies of libtetris_hip.so, one call = the work of one lane.
+//
+// `__host__ __device__` like tetris_engine.h: tetris_hip.hip wraps each body in a gfx950 kernel
+// (the product); tests/cpu_harness wraps the same bodies in plain loops so that the logic can be
+// checked against the oracle on a machine without a GPU.  Nothing in the product calls these on
+// the host.
+#pragma once
+#include "../../include/tetris_hip.h"
+#include "tetris_engine.h"
+
+namespace te {
+
+struct KArgs {
+    uint32_t* state;
+    uint32_t* gstate;
+    uint32_t* status;
+    const uint8_t* const* chunks;
+    const uint8_t* first_ok;
+    const double* combo_pow;
+    uint32_t n_draws, margin;
+    int H;
+    int n_games;              // N (stride of the SoA arrays)
+    int n;                    // lanes with work
+    const int32_t* idx;       // NULL: identity
+    const uint8_t* keys;      // [max_keys][P][n]
+    const uint8_t* lens;      // [P][n]
+    int max_keys;
+    const uint8_t* rot;       // [n]
+    const uint8_t* trans;     // [n]
+    const uint8_t* player;    // [n] or NULL
+    const int16_t* seeds;     // [n] or NULL
+    int ms;
+    uint8_t* done;            // [n]
+    uint8_t* lines;           // [P][n]
+    uint8_t* dead;            // [P][n]
+    int steps;
+    uint32_t policy_seed;
+    unsigned long long first_step;
+    unsigned long long* counters;
+    uint32_t game_offset;     // global id of slot 0 (rollout policy / seed schedule)
+};
+
+enum Mode { M_INIT, M_RESET, M_MAKE, M_FINISH, M_STEP_KEYS, M_STEP_RT, M_ROLLOUT };
+
+struct LaneCounters { unsigned long long steps, episodes, lines, sent; };
+
+TE_HD Ctx make_ctx(const KArgs& a, const uint32_t* shapes) {
+    Ctx cx;
+    cx.shapes = shapes;
+    cx.chunks = a.chunks;
+    cx.first_ok = a.first_ok;
+    cx.combo_pow = a.combo_pow;
+    cx.n_draws = a.n_draws;
+    cx.margin = a.margin;
+    cx.H = a.H;
+    cx.floor_bits = ~0u << a.H;
+    return cx;
+}
+
+template <int P>
+TE_HD void write_outputs(const KArgs& a, int i, const Game<P>& g, int done) {
+    if (a.done) a.done[i] = (uint8_t)done;
+    TE_UNROLL
+    for (int p = 0; p < P; p++) {
+        if (a.lines) a.lines[(size_t)p * a.n + i] = (uint8_t)g.pl[p].reward;
+        if (a.dead) a.dead[(size_t)p * a.n + i] = (uint8_t)g.pl[p].dead;
+    }
+}
+
+// PythonHandle.cpp:138-147 make_actions
+template <int P>
+TE_HD void make_keys(const Ctx& cx, const KArgs& a, int i, Game<P>& g) {
+    if (g.round_over) return;
+    TE_UNROLL
+    for (int p = 0; p < P; p++) {
+        Player& q = g.pl[p];
+        int len = a.lens[(size_t)p * a.n + i];
+        if (q.dead) len = 0;
+        for (int k = 0; k < len; k++) press_key(cx, q, a.keys[((size_t)k * P + p) * a.n + i]);
+    }
+}
+
+// tetris_environment.py:102-116 perform_action with the (r,t) encoding for `player`, [0] for the others
+template <int P>
+TE_HD void make_rt(const Ctx& cx, Game<P>& g, int player, int r, int t) {
+    if (g.round_over) return;
+    TE_UNROLL
+    for (int p = 0; p < P; p++)
+        if (p == player && !g.pl[p].dead) play_rt(cx, g.pl[p], r, t);
+}
+
+template <int P, int MODE>
+TE_HD void game_body(const KArgs& a, int i, const uint32_t* shapes, LaneCounters& cnt) {
+    const size_t N = (size_t)a.n_games;
+    const size_t slot = a.idx ? (size_t)a.idx[i] : (size_t)i;
+    Ctx cx = make_ctx(a, shapes);
+    Game<P> g;
+    if (MODE == M_INIT) {
+        init_game<P>(cx, g, (uint32_t)(a.seeds ? (uint16_t)a.seeds[i] : 0));
+    } else {
+        load_game<P>(a.state, a.gstate, N, slot, g);
+    }
+    if (MODE == M_RESET) {
+        reset_game<P>(cx, g, (uint32_t)(a.seeds ? (uint16_t)a.seeds[i] : 0));
+    } else if (MODE == M_MAKE) {
+        make_keys<P>(cx, a, i, g);
+    } else if (MODE == M_FINISH) {
+        int done = finish_game<P>(cx, g, a.ms);
+        write_outputs<P>(a, i, g, done);
+    } else if (MODE == M_STEP_KEYS) {
+        make_keys<P>(cx, a, i, g);
+        int done = finish_game<P>(cx, g, a.ms);
+        write_outputs<P>(a, i, g, done);
+    } else if (MODE == M_STEP_RT) {
+        make_rt<P>(cx, g, a.player ? a.player[i] : 0, a.rot[i] & 3, a.trans[i]);
+        int done = finish_game<P>(cx, g, a.ms);
+        write_outputs<P>(a, i, g, done);
+    } else if (MODE == M_ROLLOUT) {
+        // SURVEY.md §8(d) synthetic workload: worker.py:91-118 with a counter-based random policy
+        for (int s = 0; s < a.steps; s++) {
+            unsigned long long step = a.first_step + (unsigned long long)s;
+            uint32_t w[4];
+            philox4x32_10(a.policy_seed, a.game_offset + (uint32_t)slot, (uint32_t)step, (uint32_t)(step >> 32), w);
+            int r = (int)(w[0] & 3u), t = (int)(w[1] % 10u);
+            int player = P > 1 ? (int)(step % (unsigned long long)P) : 0;
+            uint32_t sent_before = 0;
+            TE_UNROLL
+            for (int p = 0; p < P; p++) sent_before += g.pl[p].lines_sent;
+            make_rt<P>(cx, g, player, r, t);
+            int done = finish_game<P>(cx, g, a.ms);
+            cnt.steps++;
+            uint32_t sent_after = 0;
+            TE_UNROLL
+            for (int p = 0; p < P; p++) {
+                sent_after += g.pl[p].lines_sent;
+                if (!g.pl[p].dead) cnt.lines += (unsigned)g.pl[p].reward;
+            }
+            cnt.sent += (sent_after - sent_before) & 0xFFFFu;
+            if (done) {
+                cnt.episodes++;
+                g.episode++;
+                reset_game<P>(cx, g, episode_seed(a.game_offset + (uint32_t)slot, g.episode));
+            }
+        }
+    }
+    store_game<P>(a.state, a.gstate, N, slot, g);
+    if (g.status) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        atomicOr(a.status, g.status);
+#else
+        *a.status |= g.status;
+#endif
+    }
+}
+
+// State views / __getstate__ (PythonHandle.h:54-82,123-308) of one game -> P records
+template <int P>
+TE_HD void observe_body(const uint32_t* state, const uint32_t* gstate, int n_games, int i, const int32_t* idx, int H,
+                        const uint32_t* shapes, tetris_record* rec, uint8_t* round_over, int8_t* last_winner) {
+    size_t slot = idx ? (size_t)idx[i] : (size_t)i;
+    Game<P> g;
+    load_game<P>(state, gstate, (size_t)n_games, slot, g);
+    if (round_over) round_over[i] = (uint8_t)g.round_over;
+    if (last_winner) last_winner[i] = (int8_t)g.last_winner;
+    if (!rec) return;
+    TE_UNROLL
+    for (int p = 0; p < P; p++) {
+        const Player& q = g.pl[p];
+        tetris_record* r = &rec[(size_t)i * P + p];
+        uint16_t* f16 = (uint16_t*)&r->field[0][0];
+        for (int y = 0; y < TETRIS_MAX_H; y++)
+            for (int c = 0; c < NCOL; c += 2) {
+                uint32_t lo = (y < H) ? ((q.col[c] >> y) & 1u) : 0u;
+                uint32_t hi = (y < H) ? ((q.col[c + 1] >> y) & 1u) : 0u;
+                f16[(y * NCOL + c) >> 1] = (uint16_t)(lo | (hi << 8));
+            }
+        uint32_t shape = shapes[((q.kind & 7) << 2) | (q.rot & 3)];
+        int val = shape_value(q.kind);
+        for (int gy = 0; gy < 4; gy++) {
+            uint32_t word = 0;
+            for (int gx = 0; gx < 4; gx++)
+                if ((shape >> (4 * gx + gy)) & 1u) word |= (uint32_t)val << (8 * gx);
+            *(uint32_t*)&r->grid[gy][0] = word;
+        }
+        r->x = (int8_t)q.x; r->y = (int8_t)q.y;
+        r->piece = (uint8_t)q.kind; r->tile = (uint8_t)(q.kind + 1);
+        r->spawn_rot = (uint8_t)(q.kind <= 6 ? spawn_rot(q.kind) : 0); r->cur_rot = (uint8_t)q.rot;
+        r->big = (uint8_t)(q.kind == 4 || q.kind == 6);
+        r->next = (uint8_t)q.next; r->dead = (uint8_t)q.dead; r->reward = (uint8_t)q.reward;
+        r->inc_count = (uint8_t)q.inc_count; r->combo_count = (uint8_t)q.combo_count;
+        r->combo_remaining = (uint16_t)q.combo_remaining;
+        r->lock_armed = (uint8_t)q.lock_armed; r->fifo_len = (uint8_t)q.qlen; r->line_count = (uint8_t)q.line_count;
+        r->fifo_overflow = (uint8_t)q.q_overflow;
+        r->time_ms = q.time_ms; r->incoming = q.incoming;
+        r->drop_delay = q.drop_delay; r->drop_time = q.drop_time; r->speedup_time = q.speedup_time;
+        r->lock_time = q.lock_time; r->min_remaining = q.min_remaining;
+        r->combo_start = q.combo_start; r->combo_time = q.combo_time;
+        for (int k = 0; k < TETRIS_FIFO_CAP; k++) { r->fifo_delay[k] = 0; r->fifo_count[k] = 0; }
+        for (int k = 0; k < FIFO_CAP; k++)
+            if (k < q.qlen) { r->fifo_delay[k] = q.qdelay[k]; r->fifo_count[k] = (int16_t)q.qcount[k]; }
+        r->lines_sent = (uint16_t)q.lines_sent; r->lines_cleared = (uint16_t)q.lines_cleared;
+        r->lines_blocked = (uint16_t)q.lines_blocked; r->garbage_cleared = (uint16_t)q.garbage_cleared;
+        r->max_combo = (uint16_t)q.max_combo; r->lines_cleared_seen = (uint16_t)q.lines_seen;
+        for (int k = 0; k < 7; k++) r->weights[k] = 0.0f;
+        r->piece_draws = q.piece_draws; r->hole_draws = q.hole_draws;
+    }
+}
+
+// PythonHandle.cpp:36-42 copy / set: raw words, blob[i][NGWORDS + P*NWORDS]; t = lane = (game i, word)
+TE_HD void snapshot_body(uint32_t* state, uint32_t* gstate, int n_games, size_t t, const int32_t* idx, int P, uint32_t* blob,
+                         int restore) {
+    const int words = NGWORDS + P * NWORDS;
+    int i = (int)(t / (size_t)words), w = (int)(t % (size_t)words);
+    size_t slot = idx ? (size_t)idx[i] : (size_t)i;
+    uint32_t* cell;
+    if (w < NGWORDS) cell = &gstate[(size_t)w * n_games + slot];
+    else {
+        int pw = w - NGWORDS, p = pw / NWORDS, ww = pw % NWORDS;
+        cell = &state[((size_t)ww * P + p) * n_games + slot];
+    }
+    if (restore) *cell = blob[t];
+    else blob[t] = *cell;
+}
+
+// data_types/state.py:11,16: Python writes State.dead
+TE_HD void set_dead_body(uint32_t* state, int n_games, int t, const int32_t* idx, int P, const uint8_t* dead) {
+    int i = t / P, p = t % P;
+    size_t slot = idx ? (size_t)idx[i] : (size_t)i;
+    uint32_t* cell = &state[((size_t)W_PIECE * P + p) * n_games + slot];
+    *cell = (*cell & ~(1u << 17)) | ((uint32_t)(dead[t] ? 1u : 0u) << 17);
+}
+
+}  // namespace te

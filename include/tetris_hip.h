@@ -1,0 +1,142 @@
+/* tetris_hip.h — C ABI of the MI355X-native batched Tetris environment (libtetris_hip.so).
+ *
+ * This is the drop-in boundary for the environment-step path of mightypirate1/DRL-Tetris.
+ * In the reference that boundary is the pybind11 module `tetris_env`
+ * (environment/game_backend/source/PythonHandle.h:113-340) consumed by
+ * environment/tetris_environment.py and environment/tetris_environment_vector.py; one
+ * `PythonHandle` = one game.  Here one `tetris_batch` = N games resident in HBM on one GPU and
+ * every entry point works on a list of game indices, so the per-env Python loops of
+ * tetris_environment_vector.py:55-120 become one kernel launch.  Each function below names the
+ * reference interface it replaces.  INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions
+ *  - plain C types only; caller owns every host buffer, the library owns all device memory.
+ *  - return value: 0 = OK, negative = error (TETRIS_E_*); tetris_last_error() gives the text
+ *    (thread-local).  There is no CPU fallback: without a HIP device tetris_create fails.
+ *  - `idx` = int32 game indices (unique within one call), NULL = games 0..n-1.
+ *  - per-player arrays are [n][P] (game-major) on the host side.
+ *  - a batch is not thread-safe; different batches are independent (one HIP stream each).
+ *  - functions ending in _dev take DEVICE pointers, enqueue on the batch's stream and return
+ *    without synchronising (zero-copy callers, benchmarks); all others are synchronous.
+ *  - board height 4..31, width 10 (the reference hard-codes 10, gamePlay.cpp:202), 1 or 2 players.
+ */
+#ifndef TETRIS_HIP_H
+#define TETRIS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TETRIS_OK 0
+#define TETRIS_E_ARG (-1)        /* bad argument */
+#define TETRIS_E_HIP (-2)        /* a HIP runtime call failed (no device, out of memory, ...) */
+#define TETRIS_E_STREAM (-3)     /* an episode outran the RNG tables (> 39 936 draws) */
+#define TETRIS_E_FIFO (-4)       /* more than 8 pending garbage packets on one board */
+
+#define TETRIS_MAX_H 32
+#define TETRIS_W 10
+#define TETRIS_FIFO_CAP 16
+
+/* Everything the reference can show about one player-board (State views PythonHandle.h:54-82 and
+ * the pickled members PythonHandle.h:123-308), flattened.  Same layout as the test oracle's record. */
+typedef struct tetris_record {
+    uint8_t  field[TETRIS_MAX_H][TETRIS_W]; /* State.field (occupancy: 0 / 1)                  */
+    uint8_t  grid[4][4];                    /* State.piece                                      */
+    int8_t   x, y;                          /* State.x, State.y                                 */
+    uint8_t  piece, tile, spawn_rot, cur_rot, big;   /* basePieces (pieces.h:7-28)             */
+    uint8_t  next, dead, reward, inc_count, combo_count;   /* State.*                           */
+    uint16_t combo_remaining;               /* State.combo_time                                 */
+    uint8_t  lock_armed, fifo_len, line_count, fifo_overflow;
+    int32_t  time_ms;
+    float    incoming;
+    int32_t  drop_delay, drop_time, speedup_time, lock_time;   /* DropDelay.h:6-18              */
+    int32_t  min_remaining;
+    int32_t  combo_start, combo_time;
+    int32_t  fifo_delay[TETRIS_FIFO_CAP];
+    int16_t  fifo_count[TETRIS_FIFO_CAP];
+    uint16_t lines_sent, lines_cleared, lines_blocked, garbage_cleared, max_combo, lines_cleared_seen;
+    float    weights[7];                    /* not tracked on the GPU (always 0)                */
+    uint32_t piece_draws, hole_draws;
+} tetris_record;
+
+typedef struct tetris_batch tetris_batch;
+
+const char *tetris_last_error(void);
+int         tetris_device_count(void);                 /* < 0 on error                          */
+int         tetris_record_size(void);
+int         tetris_snapshot_words(const tetris_batch *b);   /* uint32 words per game in a snapshot */
+
+/* replaces: tetris_env.set_pieces(map) + PythonHandle(n_players, [H, W]) for n_games games
+ * (PythonHandle.h:116-121,309; PythonHandle.cpp:5-25).  seeds[n_games] (host, NULL = all 0) stand
+ * in for time(NULL) at construction (PythonHandle.cpp:68-71).                                   */
+int tetris_create(tetris_batch **out, int n_games, int n_players, int height, int width,
+                  const uint8_t piece_map[7], int device, const int16_t *seeds);
+int tetris_destroy(tetris_batch *b);
+int tetris_sync(tetris_batch *b);                      /* drain the stream, surface sticky errors */
+
+/* replaces: PythonHandle.reset() with time(NULL) == seeds[i] (PythonHandle.cpp:49-71)           */
+int tetris_reset(tetris_batch *b, const int32_t *idx, int n, const int16_t *seeds);
+
+/* replaces: PythonHandle.make_action(list[list[int]]) (PythonHandle.cpp:138-147).
+ * keys[n][P][max_keys] uint8, lens[n][P] uint8 (host).                                          */
+int tetris_make_actions(tetris_batch *b, const int32_t *idx, int n, const uint8_t *keys,
+                        const uint8_t *lens, int max_keys);
+/* replaces: PythonHandle.finish_action(ms) (PythonHandle.cpp:149-188).  done[n]; lines[n][P] =
+ * State.reward, dead[n][P] = State.dead after the call (either may be NULL).                    */
+int tetris_finish_actions(tetris_batch *b, const int32_t *idx, int n, int ms, uint8_t *done,
+                          uint8_t *lines, uint8_t *dead);
+/* make_action + finish_action in one launch = tetris_environment.perform_action
+ * (tetris_environment.py:102-116).                                                              */
+int tetris_step_keys(tetris_batch *b, const int32_t *idx, int n, const uint8_t *keys,
+                     const uint8_t *lens, int max_keys, int ms, uint8_t *done, uint8_t *lines,
+                     uint8_t *dead);
+/* perform_action on ALL games with the SVENton (rotation, translation) encoding
+ * [8]*r + [2] + [3]*t + [7] for `player[g]`, [0] for the others (sventon_utils.py:9-13).
+ * rot/trans/player/done [N], lines/dead [N][P]; player NULL = player 0.                         */
+int tetris_step_rt(tetris_batch *b, const uint8_t *rot, const uint8_t *trans, const uint8_t *player,
+                   int ms, uint8_t *done, uint8_t *lines, uint8_t *dead);
+/* same, device pointers, asynchronous.  d_lines/d_dead are [P][N] (player-major) on the device. */
+int tetris_step_rt_dev(tetris_batch *b, const uint8_t *d_rot, const uint8_t *d_trans,
+                       const uint8_t *d_player, int ms, uint8_t *d_done, uint8_t *d_lines,
+                       uint8_t *d_dead);
+
+/* replaces: reading PythonHandle.states[p].* / __getstate__() (PythonHandle.h:54-82,123-308).
+ * records[n][P]; round_over[n]; last_winner[n] (PythonHandle.last_winner); NULLs allowed.       */
+int tetris_observe_records(tetris_batch *b, const int32_t *idx, int n, tetris_record *records,
+                           uint8_t *round_over, int8_t *last_winner);
+
+/* replaces: PythonHandle.copy() / .set() (PythonHandle.cpp:36-42): exact state incl. RNG position.
+ * blob[n][tetris_snapshot_words()] uint32 (host).  Blobs move between batches of equal geometry
+ * and piece map.                                                                                 */
+int tetris_snapshot(tetris_batch *b, const int32_t *idx, int n, uint32_t *blob);
+int tetris_restore(tetris_batch *b, const int32_t *idx, int n, const uint32_t *blob);
+/* replaces: Python writing State.dead on a live handle (data_types/state.py:11,16). dead[n][P]  */
+int tetris_set_dead(tetris_batch *b, const int32_t *idx, int n, const uint8_t *dead);
+
+/* Built-in synthetic rollout = the worker loop of drl_tetris/worker.py:91-118 with a random policy
+ * (SURVEY.md §8d): per env-step  Philox4x32-10(policy_seed; game, step) -> (r = w0 & 3,
+ * t = w1 mod 10), acting player = step mod P, perform_action, auto-reset of finished games with
+ * seed16 = (12345 + 7919 game + 104729 episode) mod 65536.  Runs `launches` kernel launches of
+ * `steps_per_launch` env-steps each on all N games (state stays in registers inside a launch).
+ * counters[4] += {env_steps, episodes, lines_cleared, garbage_lines_sent}.  elapsed_ms (optional)
+ * = HIP-event time from before the first to after the last launch on the batch's stream.        */
+int tetris_rollout_random(tetris_batch *b, int launches, int steps_per_launch, uint32_t policy_seed,
+                          uint64_t first_step, int ms, uint64_t counters[4], float *elapsed_ms);
+
+/* Global id of this batch's game 0 (default 0): the built-in rollout keys its policy and its
+ * reset-seed schedule by global game id, so that N batches on N GPUs simulate N*n_games distinct
+ * games (the reference's equivalent: N worker containers, docker-compose.yaml:27).               */
+int tetris_set_game_offset(tetris_batch *b, uint64_t first_game_id);
+
+/* plumbing for zero-copy callers (torch / another HIP library)                                   */
+void *tetris_device_state(tetris_batch *b);            /* uint32 [NWORDS][P][N]                  */
+void *tetris_stream(tetris_batch *b);                  /* hipStream_t                            */
+int   tetris_layout_words(void);                       /* NWORDS                                 */
+int   tetris_table_chunks(const tetris_batch *b);      /* RNG-table chunks currently resident    */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,291 @@
+// TEST INFRASTRUCTURE — NOT PRODUCT CODE, NOT A FALLBACK.
+//
+// Compiles the product's kernel bodies (drl-tetris_amd/csrc/tetris_kernels.h, tetris_engine.h,
+// tetris_tables.h — the exact sources hipcc builds for gfx950) with g++ and wraps them in plain
+// loops over host memory, behind the same C symbols as include/tetris_hip.h.  Purpose: let the
+// `-m "not gpu"` suite check the bitboard step logic, the RNG tables and the SoA load/store
+// against the oracle in a container that has no GPU.  Only tests/ loads this library, always by
+// explicit path; the product binding (drl-tetris_amd/capi.py) loads libtetris_hip.so and nothing else.
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../drl-tetris_amd/csrc/tetris_kernels.h"
+
+using namespace te;
+
+static thread_local std::string g_err;
+static int fail(int code, const char* msg) { g_err = msg; return code; }
+
+struct Tables {
+    uint8_t map[8] = {0};
+    int only_sz = 0;
+    std::vector<uint32_t> mt;        // [624][65536]
+    std::vector<float> w;            // [7][65536]
+    std::vector<uint8_t> first_ok;   // [65536]
+    double powtab[256];
+    std::vector<std::vector<uint8_t>> chunks;
+    std::vector<const uint8_t*> chunk_ptrs;
+    void extend() {
+        int c = (int)chunks.size();
+        chunks.emplace_back((size_t)65536 * CHUNK);
+        uint8_t* out = chunks.back().data();
+#pragma omp parallel for schedule(static)
+        for (int seed = 0; seed < 65536; seed++) {
+            uint8_t fo = 0;
+            gen_chunk_for_seed(mt.data() + seed, 65536, w.data() + seed, 65536, out + (size_t)seed * CHUNK, &fo, c, map, only_sz != 0);
+            if (c == 0) first_ok[seed] = fo;
+        }
+        chunk_ptrs.assign(MAX_CHUNKS, nullptr);
+        for (size_t i = 0; i < chunks.size(); i++) chunk_ptrs[i] = chunks[i].data();
+    }
+};
+static std::map<std::string, Tables*> g_tables;
+
+static Tables* tables_for(const uint8_t map[7]) {
+    std::string key((const char*)map, 7);
+    auto it = g_tables.find(key);
+    if (it != g_tables.end()) return it->second;
+    Tables* t = new Tables();
+    memcpy(t->map, map, 7);
+    t->only_sz = 1;
+    for (int i = 0; i < 7; i++) if (map[i] != 2 && map[i] != 3) t->only_sz = 0;
+    t->mt.resize((size_t)624 * 65536);
+    t->w.resize((size_t)7 * 65536);
+    t->first_ok.resize(65536);
+    for (int c = 0; c < 256; c++) t->powtab[c] = pow((double)c, 1.4 + (double)c * 0.01);
+#pragma omp parallel for schedule(static)
+    for (int seed = 0; seed < 65536; seed++) mt_seed(t->mt.data() + seed, 65536, (uint32_t)(int32_t)(int16_t)(uint16_t)seed);
+    t->extend();
+    t->extend();
+    g_tables[key] = t;
+    return t;
+}
+
+struct tetris_batch {
+    int N, P, H;
+    std::vector<uint32_t> state, gstate;
+    uint32_t status = 0;
+    uint32_t margin = 64;
+    uint32_t game_offset = 0;
+    Tables* tab;
+};
+
+static KArgs base_args(tetris_batch* b, int n, const int32_t* idx) {
+    KArgs a;
+    memset(&a, 0, sizeof a);
+    a.state = b->state.data(); a.gstate = b->gstate.data(); a.status = &b->status;
+    a.chunks = b->tab->chunk_ptrs.data(); a.first_ok = b->tab->first_ok.data(); a.combo_pow = b->tab->powtab;
+    a.n_draws = (uint32_t)b->tab->chunks.size() * CHUNK; a.margin = b->margin;
+    a.H = b->H; a.n_games = b->N; a.n = n; a.idx = idx; a.game_offset = b->game_offset;
+    return a;
+}
+
+template <int MODE>
+static void run(tetris_batch* b, const KArgs& a, LaneCounters* total = nullptr) {
+    LaneCounters sum = {0, 0, 0, 0};
+    for (int i = 0; i < a.n; i++) {
+        LaneCounters c = {0, 0, 0, 0};
+        if (b->P == 1) game_body<1, MODE>(a, i, SHAPES.s, c);
+        else game_body<2, MODE>(a, i, SHAPES.s, c);
+        sum.steps += c.steps; sum.episodes += c.episodes; sum.lines += c.lines; sum.sent += c.sent;
+    }
+    if (total) *total = sum;
+}
+
+static int finish_call(tetris_batch* b) {
+    uint32_t st = b->status;
+    if (st & ST_STREAM_EXHAUSTED) return fail(TETRIS_E_STREAM, "an episode ran past the RNG tables");
+    if (st & ST_FIFO_OVERFLOW) return fail(TETRIS_E_FIFO, "garbage FIFO overflow");
+    if (st & ST_NEED_EXTEND) {
+        if ((int)b->tab->chunks.size() >= MAX_CHUNKS) return fail(TETRIS_E_STREAM, "MAX_CHUNKS reached");
+        b->tab->extend();
+        b->status = 0;
+    }
+    return TETRIS_OK;
+}
+
+// host [n][P][K] -> [K][P][n], [n][P] -> [P][n]
+struct KeyStage { std::vector<uint8_t> k, l; };
+static int stage_keys(tetris_batch* b, int n, const uint8_t* keys, const uint8_t* lens, int max_keys, KArgs& a, KeyStage& s) {
+    const int P = b->P;
+    s.k.assign((size_t)n * P * max_keys, 0); s.l.assign((size_t)n * P, 0);
+    for (int i = 0; i < n; i++)
+        for (int p = 0; p < P; p++) {
+            int len = lens[(size_t)i * P + p];
+            if (len > max_keys) return fail(TETRIS_E_ARG, "lens > max_keys");
+            s.l[(size_t)p * n + i] = (uint8_t)len;
+            for (int k = 0; k < max_keys; k++) s.k[((size_t)k * P + p) * n + i] = keys[((size_t)i * P + p) * max_keys + k];
+        }
+    a.keys = s.k.data(); a.lens = s.l.data(); a.max_keys = max_keys;
+    return TETRIS_OK;
+}
+
+struct OutStage { std::vector<uint8_t> done, lines, dead; };
+static void stage_out(tetris_batch* b, int n, KArgs& a, OutStage& o) {
+    o.done.assign(n, 0); o.lines.assign((size_t)n * b->P, 0); o.dead.assign((size_t)n * b->P, 0);
+    a.done = o.done.data(); a.lines = o.lines.data(); a.dead = o.dead.data();
+}
+static void fetch_out(tetris_batch* b, int n, const OutStage& o, uint8_t* done, uint8_t* lines, uint8_t* dead) {
+    if (done) memcpy(done, o.done.data(), n);
+    for (int i = 0; i < n; i++)
+        for (int p = 0; p < b->P; p++) {
+            if (lines) lines[(size_t)i * b->P + p] = o.lines[(size_t)p * n + i];
+            if (dead) dead[(size_t)i * b->P + p] = o.dead[(size_t)p * n + i];
+        }
+}
+
+extern "C" {
+
+const char* tetris_last_error(void) { return g_err.c_str(); }
+int tetris_device_count(void) { return 0; }
+int tetris_record_size(void) { return (int)sizeof(tetris_record); }
+int tetris_layout_words(void) { return NWORDS; }
+int tetris_snapshot_words(const tetris_batch* b) { return b ? NGWORDS + b->P * NWORDS : 0; }
+int tetris_table_chunks(const tetris_batch* b) { return b ? (int)b->tab->chunks.size() : 0; }
+void* tetris_device_state(tetris_batch* b) { return b ? b->state.data() : nullptr; }
+void* tetris_stream(tetris_batch*) { return nullptr; }
+int tetris_is_cpu_harness(void) { return 1; }
+
+int tetris_create(tetris_batch** out, int n_games, int n_players, int height, int width, const uint8_t piece_map[7], int,
+                  const int16_t* seeds) {
+    if (!out) return fail(TETRIS_E_ARG, "out is NULL");
+    *out = nullptr;
+    if (n_games < 1) return fail(TETRIS_E_ARG, "n_games must be >= 1");
+    if (n_players != 1 && n_players != 2) return fail(TETRIS_E_ARG, "n_players must be 1 or 2");
+    if (height < 4 || height > MAX_H) return fail(TETRIS_E_ARG, "height must be in [4, 31]");
+    if (width != NCOL) return fail(TETRIS_E_ARG, "width must be 10");
+    if (!piece_map) return fail(TETRIS_E_ARG, "piece_map is NULL");
+    for (int i = 0; i < 7; i++) if (piece_map[i] > 6) return fail(TETRIS_E_ARG, "piece_map entries must be 0..6");
+    tetris_batch* b = new tetris_batch();
+    b->N = n_games; b->P = n_players; b->H = height;
+    b->state.assign((size_t)NWORDS * n_players * n_games, 0);
+    b->gstate.assign((size_t)NGWORDS * n_games, 0);
+    b->tab = tables_for(piece_map);
+    KArgs a = base_args(b, n_games, nullptr);
+    a.seeds = seeds;
+    run<M_INIT>(b, a);
+    int rc = finish_call(b);
+    if (rc) { delete b; return rc; }
+    *out = b;
+    return TETRIS_OK;
+}
+
+int tetris_destroy(tetris_batch* b) { delete b; return TETRIS_OK; }
+int tetris_sync(tetris_batch* b) { return finish_call(b); }
+int tetris_set_game_offset(tetris_batch* b, uint64_t first) { b->game_offset = (uint32_t)first; return TETRIS_OK; }
+
+static int check_idx(tetris_batch* b, const int32_t* idx, int n) {
+    if (n < 0 || (!idx && n > b->N)) return fail(TETRIS_E_ARG, "n out of range");
+    if (idx) for (int i = 0; i < n; i++) if (idx[i] < 0 || idx[i] >= b->N) return fail(TETRIS_E_ARG, "game index out of range");
+    return TETRIS_OK;
+}
+
+int tetris_reset(tetris_batch* b, const int32_t* idx, int n, const int16_t* seeds) {
+    int rc = check_idx(b, idx, n); if (rc) return rc;
+    KArgs a = base_args(b, n, idx); a.seeds = seeds;
+    run<M_RESET>(b, a);
+    return finish_call(b);
+}
+
+int tetris_make_actions(tetris_batch* b, const int32_t* idx, int n, const uint8_t* keys, const uint8_t* lens, int max_keys) {
+    int rc = check_idx(b, idx, n); if (rc) return rc;
+    KArgs a = base_args(b, n, idx); KeyStage s;
+    if ((rc = stage_keys(b, n, keys, lens, max_keys, a, s))) return rc;
+    run<M_MAKE>(b, a);
+    return finish_call(b);
+}
+
+int tetris_finish_actions(tetris_batch* b, const int32_t* idx, int n, int ms, uint8_t* done, uint8_t* lines, uint8_t* dead) {
+    int rc = check_idx(b, idx, n); if (rc) return rc;
+    KArgs a = base_args(b, n, idx); a.ms = ms; OutStage o; stage_out(b, n, a, o);
+    run<M_FINISH>(b, a);
+    fetch_out(b, n, o, done, lines, dead);
+    return finish_call(b);
+}
+
+int tetris_step_keys(tetris_batch* b, const int32_t* idx, int n, const uint8_t* keys, const uint8_t* lens, int max_keys, int ms,
+                     uint8_t* done, uint8_t* lines, uint8_t* dead) {
+    int rc = check_idx(b, idx, n); if (rc) return rc;
+    KArgs a = base_args(b, n, idx); a.ms = ms; KeyStage s; OutStage o;
+    if ((rc = stage_keys(b, n, keys, lens, max_keys, a, s))) return rc;
+    stage_out(b, n, a, o);
+    run<M_STEP_KEYS>(b, a);
+    fetch_out(b, n, o, done, lines, dead);
+    return finish_call(b);
+}
+
+int tetris_step_rt(tetris_batch* b, const uint8_t* rot, const uint8_t* trans, const uint8_t* player, int ms, uint8_t* done,
+                   uint8_t* lines, uint8_t* dead) {
+    if (!rot || !trans) return fail(TETRIS_E_ARG, "rot/trans are NULL");
+    if (player) for (int i = 0; i < b->N; i++) if (player[i] >= b->P) return fail(TETRIS_E_ARG, "player index out of range");
+    KArgs a = base_args(b, b->N, nullptr); a.ms = ms; a.rot = rot; a.trans = trans; a.player = player;
+    OutStage o; stage_out(b, b->N, a, o);
+    run<M_STEP_RT>(b, a);
+    fetch_out(b, b->N, o, done, lines, dead);
+    return finish_call(b);
+}
+
+int tetris_step_rt_dev(tetris_batch* b, const uint8_t* rot, const uint8_t* trans, const uint8_t* player, int ms, uint8_t* done,
+                       uint8_t* lines, uint8_t* dead) {
+    KArgs a = base_args(b, b->N, nullptr); a.ms = ms; a.rot = rot; a.trans = trans; a.player = player;
+    a.done = done; a.lines = lines; a.dead = dead;
+    run<M_STEP_RT>(b, a);
+    return TETRIS_OK;
+}
+
+int tetris_observe_records(tetris_batch* b, const int32_t* idx, int n, tetris_record* records, uint8_t* round_over,
+                           int8_t* last_winner) {
+    int rc = check_idx(b, idx, n); if (rc) return rc;
+    for (int i = 0; i < n; i++) {
+        if (b->P == 1) observe_body<1>(b->state.data(), b->gstate.data(), b->N, i, idx, b->H, SHAPES.s, records, round_over, last_winner);
+        else observe_body<2>(b->state.data(), b->gstate.data(), b->N, i, idx, b->H, SHAPES.s, records, round_over, last_winner);
+    }
+    return TETRIS_OK;
+}
+
+int tetris_snapshot(tetris_batch* b, const int32_t* idx, int n, uint32_t* blob) {
+    int rc = check_idx(b, idx, n); if (rc) return rc;
+    size_t total = (size_t)n * (NGWORDS + b->P * NWORDS);
+    for (size_t t = 0; t < total; t++) snapshot_body(b->state.data(), b->gstate.data(), b->N, t, idx, b->P, blob, 0);
+    return TETRIS_OK;
+}
+int tetris_restore(tetris_batch* b, const int32_t* idx, int n, const uint32_t* blob) {
+    int rc = check_idx(b, idx, n); if (rc) return rc;
+    size_t total = (size_t)n * (NGWORDS + b->P * NWORDS);
+    for (size_t t = 0; t < total; t++) snapshot_body(b->state.data(), b->gstate.data(), b->N, t, idx, b->P, (uint32_t*)blob, 1);
+    return TETRIS_OK;
+}
+int tetris_set_dead(tetris_batch* b, const int32_t* idx, int n, const uint8_t* dead) {
+    int rc = check_idx(b, idx, n); if (rc) return rc;
+    for (int t = 0; t < n * b->P; t++) set_dead_body(b->state.data(), b->N, t, idx, b->P, dead);
+    return TETRIS_OK;
+}
+
+int tetris_rollout_random(tetris_batch* b, int launches, int steps_per_launch, uint32_t policy_seed, uint64_t first_step, int ms,
+                          uint64_t counters[4], float* elapsed_ms) {
+    if (launches < 1 || steps_per_launch < 1 || steps_per_launch > 256) return fail(TETRIS_E_ARG, "launches/steps_per_launch");
+    const int group = 256 / steps_per_launch;
+    const uint32_t saved = b->margin;
+    b->margin = (uint32_t)(2 * group * steps_per_launch + 16);
+    if (b->margin < saved) b->margin = saved;
+    int rc = TETRIS_OK;
+    for (int l = 0; l < launches && !rc; l++) {
+        KArgs a = base_args(b, b->N, nullptr);
+        a.ms = ms; a.steps = steps_per_launch; a.policy_seed = policy_seed;
+        a.first_step = first_step + (uint64_t)l * (uint64_t)steps_per_launch;
+        LaneCounters c;
+        run<M_ROLLOUT>(b, a, &c);
+        if (counters) { counters[0] += c.steps; counters[1] += c.episodes; counters[2] += c.lines; counters[3] += c.sent; }
+        if ((l + 1) % group == 0 || l + 1 == launches) rc = finish_call(b);
+    }
+    b->margin = saved;
+    if (elapsed_ms) *elapsed_ms = 0.0f;
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,21 @@
+"""The bitboard engine against the compiled reference's golden traces (tests/golden, made by
+make_golden.py from oracle/_ref): every event, every field the reference can show (cells compared
+as occupancy).  `harness` = same kernel bodies built by g++ (CPU suite); `hip` = the product on GPU."""
+import pytest
+
+from tests import engines, replay
+
+FIELDS = replay.VISIBLE + replay.HIDDEN
+
+
+@pytest.mark.parametrize("kind", engines.ENGINE_PARAMS)
+@pytest.mark.parametrize("name", replay.trace_names())
+def test_engine_replays_reference_trace(kind, name):
+    trace = replay.load_trace(name)
+    max_events = None if kind == "harness" or name in ("greedy_2p", "keys_2p", "greedy_1p", "drop_2p", "rt_2p_sz") else 700
+
+    def factory(P, H, W, pieces, seed):
+        return engines.make(kind, 1, P, H, pieces, seeds=seed)
+
+    n = replay.replay(trace, factory, fields=FIELDS, occupancy_only=True, max_events=max_events)
+    assert n > 0

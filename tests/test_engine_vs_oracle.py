@@ -1,0 +1,175 @@
+"""The bitboard engine against the oracle on seeded batches: same seeds, same action stream, full
+hidden state compared (incl. timers, garbage FIFO, RNG draw counters).  Sizes are chosen so the
+oracle finishes in seconds; the full BASELINE sizes are in test_full_size.py."""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from tests import engines
+
+
+def _pair(kind, n, P, H=20, pieces=(0, 1, 2, 3, 4, 5, 6), seed_base=0):
+    seeds = orc.episode_seed(np.arange(n) + seed_base, 0)
+    eng = engines.make(kind, n, P, H, pieces, seeds=seeds)
+    ref = engines.make("oracle", n, P, H, pieces, seeds=seeds)
+    return eng, ref
+
+
+@pytest.mark.parametrize("kind", engines.ENGINE_PARAMS)
+@pytest.mark.parametrize("P,H", [(1, 20), (2, 20), (2, 22)])
+def test_step_rt_with_resets(kind, P, H):
+    n = 4096 if kind == "hip" else 384
+    steps = 160
+    eng, ref = _pair(kind, n, P, H)
+    engines.assert_same_state(eng, ref, where="after create")
+    rng = np.random.default_rng(5 + P)
+    episode = np.zeros(n, np.int64)
+    for s in range(steps):
+        rot = rng.integers(0, 4, n).astype(np.uint8)
+        trans = rng.integers(0, 10, n).astype(np.uint8)
+        player = rng.integers(0, P, n).astype(np.uint8) if s % 3 == 0 else np.full(n, s % P, np.uint8)
+        d1, lines, dead = eng.step_rt(rot, trans, player, full=True)
+        d2 = ref.step_rt(rot, trans, player)
+        assert np.array_equal(d1, d2), f"done differs at step {s}"
+        if s % 16 == 15:
+            engines.assert_same_state(eng, ref, where=f"step {s}")
+            rec = ref.observe()[0]
+            assert np.array_equal(lines, rec["reward"]) and np.array_equal(dead, rec["dead"])
+        idx = np.nonzero(d2)[0].astype(np.int32)
+        if s % 40 == 39:                      # also reset some running games (last_winner = -1 path)
+            idx = np.union1d(idx, np.arange(0, n, 7)).astype(np.int32)
+        if len(idx):
+            episode[idx] += 1
+            sd = orc.episode_seed(idx, episode[idx])
+            eng.reset(idx, sd)
+            ref.reset(idx, sd)
+    engines.assert_same_state(eng, ref, where="end")
+
+
+@pytest.mark.parametrize("kind", engines.ENGINE_PARAMS)
+@pytest.mark.parametrize("P", [1, 2])
+def test_random_key_sequences(kind, P):
+    """General key interpreter (PythonHandle.cpp:73-112): every key 0..10, soft drops, keys after a lock,
+    empty lists, make/finish called separately and fused, on subsets of games."""
+    n = 2048 if kind == "hip" else 256
+    K = 20
+    eng, ref = _pair(kind, n, P, 20, seed_base=1000)
+    rng = np.random.default_rng(11)
+    episode = np.zeros(n, np.int64)
+    for s in range(120):
+        lens = rng.integers(0, K - 2, (n, P)).astype(np.uint8)
+        keys = rng.integers(0, 11, (n, P, K)).astype(np.uint8)
+        lock = rng.random((n, P)) < 0.7
+        for p in range(P):
+            rows = np.nonzero(lock[:, p])[0]
+            keys[rows, p, lens[rows, p]] = 7
+            lens[rows, p] += 1
+        if P == 2:                                 # usually only one player acts (the other gets [0])
+            idle = rng.integers(0, 2, n)
+            solo = rng.random(n) < 0.8
+            for p in range(2):
+                rows = np.nonzero(solo & (idle == p))[0]
+                keys[rows, p, 0] = 0
+                lens[rows, p] = 1
+        if s % 2 == 0:
+            done, _, _ = eng.step_keys(keys, lens)
+        else:
+            sub = np.sort(rng.choice(n, n // 2, replace=False)).astype(np.int32)
+            rest = np.setdiff1d(np.arange(n), sub).astype(np.int32)
+            eng.make_actions(keys[sub], lens[sub], idx=sub)
+            eng.make_actions(keys[rest], lens[rest], idx=rest)
+            done = eng.finish_actions(400)
+        ref.make_actions(keys, lens)
+        d2 = ref.finish_actions(400)
+        assert np.array_equal(done, d2), f"done differs at step {s}"
+        if s % 10 == 9:
+            engines.assert_same_state(eng, ref, where=f"step {s}")
+        idx = np.nonzero(d2)[0].astype(np.int32)
+        if len(idx):
+            episode[idx] += 1
+            sd = orc.episode_seed(idx + 1000, episode[idx])
+            eng.reset(idx, sd)
+            ref.reset(idx, sd)
+    engines.assert_same_state(eng, ref, where="end")
+
+
+@pytest.mark.parametrize("kind", engines.ENGINE_PARAMS)
+def test_simulate_without_finalize_and_snapshot_restore(kind):
+    """tetris_environment.simulate_actions (tetris_environment.py:87-100): copy, make_action without
+    finish_action, look, set back.  Also copy/set across games and batches (PythonHandle.cpp:36-42)."""
+    n, P = 128, 2
+    eng, ref = _pair(kind, n, P)
+    rng = np.random.default_rng(3)
+    for s in range(30):
+        rot, trans = rng.integers(0, 4, n).astype(np.uint8), rng.integers(0, 10, n).astype(np.uint8)
+        eng.step_rt(rot, trans, s % 2)
+        ref.step_rt(rot, trans, s % 2)
+    anchor = eng.snapshot()
+    ref_anchor = engines.make("oracle", n, P)
+    ref_anchor.copy_from(ref)
+    keys = np.zeros((n, P, 8), np.uint8)
+    lens = np.ones((n, P), np.uint8)
+    keys[:, 0, :4] = [8, 2, 3, 7]
+    lens[:, 0] = 4
+    eng.make_actions(keys, lens)
+    ref.make_actions(keys, lens)
+    engines.assert_same_state(eng, ref, where="after make without finish")
+    eng.restore(anchor)
+    ref.copy_from(ref_anchor)
+    engines.assert_same_state(eng, ref, where="after restore")
+    # restore game 5's snapshot into games 0..9 of a second batch, then play on: RNG position travels
+    other = engines.make(kind, 16, P)
+    other_ref = engines.make("oracle", 16, P)
+    other.restore(np.repeat(anchor[5:6], 10, axis=0), idx=np.arange(10, dtype=np.int32))
+    other_ref.copy_from(ref_anchor, dst_idx=np.arange(10), src_idx=np.full(10, 5))
+    for s in range(40):
+        rot, trans = rng.integers(0, 4, 16).astype(np.uint8), rng.integers(0, 10, 16).astype(np.uint8)
+        other.step_rt(rot, trans, s % 2)
+        other_ref.step_rt(rot, trans, s % 2)
+    engines.assert_same_state(other, other_ref, where="restored games played on")
+    # state.lock(): Python writes dead = 1 into a snapshot's players (data_types/state.py:9-12)
+    dead = np.ones((n, P), np.uint8)
+    eng.set_dead(dead)
+    ref.set_dead(dead)
+    eng.step_rt(rot[:1].repeat(n), trans[:1].repeat(n), 0)
+    ref.step_rt(rot[:1].repeat(n), trans[:1].repeat(n), 0)
+    engines.assert_same_state(eng, ref, where="locked state does not move")
+
+
+@pytest.mark.parametrize("kind", engines.ENGINE_PARAMS)
+def test_rng_tables_extend_past_two_chunks(kind):
+    """An episode that outlives the resident RNG-table chunks (624 draws each): key [1] never locks, so
+    every finish_action deals one piece."""
+    n, P = 4, 1
+    eng, ref = _pair(kind, n, P, seed_base=31000)
+    keys = np.ones((n, P, 1), np.uint8)
+    lens = np.ones((n, P), np.uint8)
+    for s in range(1400):
+        eng.step_keys(keys, lens)
+        ref.make_actions(keys, lens)
+        ref.finish_actions(400)
+        if s % 100 == 99 or s > 1180:
+            a, b = eng.observe()[0], ref.observe()[0]
+            assert np.array_equal(a["next"], b["next"]) and np.array_equal(a["piece_draws"], b["piece_draws"]), s
+    assert eng.table_chunks >= 3            # tables are shared per process: another test may have grown them already
+    engines.assert_same_state(eng, ref, where="end")
+
+
+@pytest.mark.parametrize("kind", engines.ENGINE_PARAMS)
+@pytest.mark.parametrize("P", [1, 2])
+def test_rollout_random_matches_oracle(kind, P):
+    """The built-in synthetic rollout (SURVEY §8d policy + auto-reset) against the oracle's: counters and
+    final state, fused (many steps per launch) and unfused (one step per launch) give the same result."""
+    n = 2048 if kind == "hip" else 192
+    seeds = orc.episode_seed(np.arange(n), 0)
+    eng = engines.make(kind, n, P, seeds=seeds)
+    eng2 = engines.make(kind, n, P, seeds=seeds)
+    ref = engines.make("oracle", n, P, seeds=seeds)
+    c1, _ = eng.rollout_random(6, 32)               # 192 steps, fused
+    c2a, _ = eng2.rollout_random(100, 1)            # 100 + 92 steps, one per launch
+    c2b, _ = eng2.rollout_random(92, 1, first_step=100)
+    ep, c3 = ref.rollout_random(192)
+    assert c1.tolist() == c3.tolist() == (c2a + c2b).tolist()
+    assert int(c1[0]) == n * 192 and int(c1[1]) > 0
+    engines.assert_same_state(eng, ref, where="fused rollout")
+    engines.assert_same_state(eng2, ref, where="unfused rollout")
