@@ -70,7 +70,8 @@ def cpu_baseline(n_players, height, budget_s):
                "sample": f"reference C++ backend (oracle/_ref, -O0 as the reference builds it), {n} envs x {s} steps, "
                          f"{n_players} player(s), {height}x10, same policy/seeds, bare make_action+finish_action+reset loop from Python"}
     # the C restatement (port), one thread and all cores
-    cores = os.cpu_count() or 1
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    cores = min(cores, 32)
     nb = 4096
     b = orc.OracleBatch(nb, n_players, height, 10, seeds=orc.episode_seed(np.arange(nb), 0))
     port = {}

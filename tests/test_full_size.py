@@ -19,7 +19,7 @@ def test_64k_boards_rollout_bit_exact(P, steps):
     eng = engines.make("hip", n, P, seeds=seeds)
     ref = engines.make("oracle", n, P, seeds=seeds)
     c_gpu, _ = eng.rollout_random(steps, 1)
-    _, c_ref = ref.rollout_random(steps, threads=os.cpu_count() or 1)
+    _, c_ref = ref.rollout_random(steps, threads=min(32, len(os.sched_getaffinity(0))))
     assert c_gpu.tolist() == c_ref.tolist()
     for lo in range(0, n, 8192):
         idx = np.arange(lo, lo + 8192, dtype=np.int32)
@@ -41,7 +41,8 @@ def test_batch_independence_and_order_invariance():
         db = b.step_rt(rot[perm], trans[perm], s % 2)
         assert np.array_equal(da[perm], db)
     ra, rb = a.observe()[0], b.observe()[0]
-    assert ra[perm].tobytes() == rb.tobytes()
+    for f in ra.dtype.names:                      # field-wise: struct padding is indeterminate
+        assert np.array_equal(ra[f][perm], rb[f]), f
     # snapshot -> restore is the identity on the raw state words
     blob = a.snapshot()
     a.restore(blob)
