@@ -34,6 +34,16 @@ TE_HD int clz32(uint32_t v) { return __builtin_clz(v); }
 TE_HD int ctz32(uint32_t v) { return __builtin_ctz(v); }
 TE_HD int clz32(uint32_t v) { return __builtin_clz(v); }
 #endif
+// State words are touched exactly once per launch and next read by another launch (possibly on another
+// XCD): stream them past the caches (`nt`), which also leaves no dirty L2 lines for the end-of-kernel
+// write-back to drain.
+#if defined(__HIP_DEVICE_COMPILE__)
+TE_HD uint32_t ld_stream(const uint32_t* p) { return __builtin_nontemporal_load(p); }
+TE_HD void st_stream(uint32_t* p, uint32_t v) { __builtin_nontemporal_store(v, p); }
+#else
+TE_HD uint32_t ld_stream(const uint32_t* p) { return *p; }
+TE_HD void st_stream(uint32_t* p, uint32_t v) { *p = v; }
+#endif
 TE_HD int imin(int a, int b) { return a < b ? a : b; }
 TE_HD int imax(int a, int b) { return a > b ? a : b; }
 TE_HD uint32_t f2u(float f) { union { float f; uint32_t u; } v; v.f = f; return v.u; }
@@ -80,7 +90,7 @@ constexpr ShapeTable SHAPES = make_shape_table();
 // ---------------------------------------------------------------- context (read-only per launch)
 struct Ctx {
     const uint32_t* shapes;          // 32 shape words (LDS on the GPU)
-    const uint8_t* const* chunks;    // RNG table chunks: chunks[c][seed16 * 624 + r]
+    const uint8_t* table;            // RNG table, one allocation: table[(chunk * 65536 + seed16) * 624 + r]
     const uint8_t* first_ok;         // [65536]
     const double* combo_pow;         // [256] pow(c, 1.4 + 0.01 c) from the host libm (Combo.cpp:41)
     uint32_t n_draws;                // draws available per seed = n_chunks * 624
@@ -104,7 +114,12 @@ struct Player {
     int32_t qcount[FIFO_CAP];
     int32_t qdelay[FIFO_CAP];
     int q_loaded;                    // FIFO words were read from memory (qlen > 0 at load time)
+    uint32_t pf_next;                // prefetched table byte of draw `piece_draws` (valid while pf_ok)
+    int pf_ok;
 };
+
+// table bytes a reset will need, fetched ahead of time (see prefetch_reset)
+struct ResetPrefetch { uint32_t seed16, first_ok, b0, b1; int ok; };
 
 template <int P>
 struct Game {
@@ -119,85 +134,86 @@ struct Game {
 // state[(w * P + p) * n + slot]; game words at gstate[w * n + slot]
 template <int P>
 TE_HD void load_game(const uint32_t* state, const uint32_t* gstate, size_t n, size_t slot, Game<P>& g) {
-    uint32_t meta = gstate[(size_t)G_META * n + slot];
+    uint32_t meta = ld_stream(&gstate[(size_t)G_META * n + slot]);
     g.seed16 = meta & 0xFFFFu;
     g.round_over = (meta >> 16) & 1;
     g.last_winner = (int)((meta >> 17) & 0xF) - 1;
-    g.episode = gstate[(size_t)G_EPISODE * n + slot];
+    g.episode = ld_stream(&gstate[(size_t)G_EPISODE * n + slot]);
     g.status = 0;
     TE_UNROLL
     for (int p = 0; p < P; p++) {
         Player& q = g.pl[p];
         const uint32_t* s = state + (size_t)p * n + slot;
         const size_t ws = (size_t)P * n;
-        for (int c = 0; c < NCOL; c++) q.col[c] = s[(size_t)(W_COL0 + c) * ws];
-        uint32_t w = s[(size_t)W_PIECE * ws];
+        for (int c = 0; c < NCOL; c++) q.col[c] = ld_stream(&s[(size_t)(W_COL0 + c) * ws]);
+        uint32_t w = ld_stream(&s[(size_t)W_PIECE * ws]);
         q.kind = w & 7; q.rot = (w >> 3) & 3; q.x = (int)((w >> 5) & 15) - 4; q.y = (w >> 9) & 31;
         q.next = (w >> 14) & 7; q.dead = (w >> 17) & 1; q.lock_armed = (w >> 18) & 1; q.reward = (w >> 19) & 255;
-        w = s[(size_t)W_MISC * ws];
+        w = ld_stream(&s[(size_t)W_MISC * ws]);
         q.inc_count = w & 255; q.combo_count = (w >> 8) & 255; q.line_count = (w >> 16) & 255;
         q.qlen = (w >> 24) & 15; q.q_overflow = (w >> 28) & 1;
-        q.time_ms = (int32_t)s[(size_t)W_TIME * ws];
-        w = s[(size_t)W_DROPCOMBO * ws];
+        q.time_ms = (int32_t)ld_stream(&s[(size_t)W_TIME * ws]);
+        w = ld_stream(&s[(size_t)W_DROPCOMBO * ws]);
         q.drop_delay = w & 0xFFFF; q.combo_remaining = w >> 16;
-        q.drop_time = (int32_t)s[(size_t)W_DROP_TIME * ws];
-        q.speedup_time = (int32_t)s[(size_t)W_SPEEDUP_TIME * ws];
-        q.lock_time = (int32_t)s[(size_t)W_LOCK_TIME * ws];
-        q.combo_start = (int32_t)s[(size_t)W_COMBO_START * ws];
-        q.combo_time = (int32_t)s[(size_t)W_COMBO_TIME * ws];
-        q.incoming = u2f(s[(size_t)W_INCOMING * ws]);
-        q.min_remaining = (int32_t)s[(size_t)W_MIN_REMAINING * ws];
-        q.piece_draws = s[(size_t)W_PIECE_DRAWS * ws];
-        q.hole_draws = s[(size_t)W_HOLE_DRAWS * ws];
-        w = s[(size_t)W_STATS0 * ws]; q.lines_sent = w & 0xFFFF; q.lines_cleared = w >> 16;
-        w = s[(size_t)W_STATS1 * ws]; q.lines_blocked = w & 0xFFFF; q.max_combo = w >> 16;
-        w = s[(size_t)W_STATS2 * ws]; q.lines_seen = w & 0xFFFF; q.garbage_cleared = w >> 16;
+        q.drop_time = (int32_t)ld_stream(&s[(size_t)W_DROP_TIME * ws]);
+        q.speedup_time = (int32_t)ld_stream(&s[(size_t)W_SPEEDUP_TIME * ws]);
+        q.lock_time = (int32_t)ld_stream(&s[(size_t)W_LOCK_TIME * ws]);
+        q.combo_start = (int32_t)ld_stream(&s[(size_t)W_COMBO_START * ws]);
+        q.combo_time = (int32_t)ld_stream(&s[(size_t)W_COMBO_TIME * ws]);
+        q.incoming = u2f(ld_stream(&s[(size_t)W_INCOMING * ws]));
+        q.min_remaining = (int32_t)ld_stream(&s[(size_t)W_MIN_REMAINING * ws]);
+        q.piece_draws = ld_stream(&s[(size_t)W_PIECE_DRAWS * ws]);
+        q.hole_draws = ld_stream(&s[(size_t)W_HOLE_DRAWS * ws]);
+        w = ld_stream(&s[(size_t)W_STATS0 * ws]); q.lines_sent = w & 0xFFFF; q.lines_cleared = w >> 16;
+        w = ld_stream(&s[(size_t)W_STATS1 * ws]); q.lines_blocked = w & 0xFFFF; q.max_combo = w >> 16;
+        w = ld_stream(&s[(size_t)W_STATS2 * ws]); q.lines_seen = w & 0xFFFF; q.garbage_cleared = w >> 16;
         q.q_loaded = q.qlen > 0;
+        q.pf_ok = 0; q.pf_next = 0;
         for (int i = 0; i < FIFO_CAP; i++) { q.qcount[i] = 0; q.qdelay[i] = 0; }
         if (q.q_loaded) {
             for (int i = 0; i < FIFO_CAP / 2; i++) {
-                uint32_t cw = s[(size_t)(W_FIFO_COUNT0 + i) * ws];
+                uint32_t cw = ld_stream(&s[(size_t)(W_FIFO_COUNT0 + i) * ws]);
                 q.qcount[2 * i] = (int16_t)(cw & 0xFFFF);
                 q.qcount[2 * i + 1] = (int16_t)(cw >> 16);
             }
-            for (int i = 0; i < FIFO_CAP; i++) q.qdelay[i] = (int32_t)s[(size_t)(W_FIFO_DELAY0 + i) * ws];
+            for (int i = 0; i < FIFO_CAP; i++) q.qdelay[i] = (int32_t)ld_stream(&s[(size_t)(W_FIFO_DELAY0 + i) * ws]);
         }
     }
 }
 
 template <int P>
 TE_HD void store_game(uint32_t* state, uint32_t* gstate, size_t n, size_t slot, const Game<P>& g) {
-    gstate[(size_t)G_META * n + slot] = g.seed16 | ((uint32_t)g.round_over << 16) | ((uint32_t)(g.last_winner + 1) << 17);
-    gstate[(size_t)G_EPISODE * n + slot] = g.episode;
+    st_stream(&gstate[(size_t)G_META * n + slot], g.seed16 | ((uint32_t)g.round_over << 16) | ((uint32_t)(g.last_winner + 1) << 17));
+    st_stream(&gstate[(size_t)G_EPISODE * n + slot], g.episode);
     TE_UNROLL
     for (int p = 0; p < P; p++) {
         const Player& q = g.pl[p];
         uint32_t* s = state + (size_t)p * n + slot;
         const size_t ws = (size_t)P * n;
-        for (int c = 0; c < NCOL; c++) s[(size_t)(W_COL0 + c) * ws] = q.col[c];
-        s[(size_t)W_PIECE * ws] = (uint32_t)q.kind | ((uint32_t)q.rot << 3) | ((uint32_t)(q.x + 4) << 5) | ((uint32_t)q.y << 9) |
+        for (int c = 0; c < NCOL; c++) st_stream(&s[(size_t)(W_COL0 + c) * ws], q.col[c]);
+        st_stream(&s[(size_t)W_PIECE * ws], (uint32_t)q.kind | ((uint32_t)q.rot << 3) | ((uint32_t)(q.x + 4) << 5) | ((uint32_t)q.y << 9) |
                                   ((uint32_t)q.next << 14) | ((uint32_t)q.dead << 17) | ((uint32_t)q.lock_armed << 18) |
-                                  ((uint32_t)(q.reward & 255) << 19);
-        s[(size_t)W_MISC * ws] = (uint32_t)(q.inc_count & 255) | ((uint32_t)(q.combo_count & 255) << 8) |
-                                 ((uint32_t)(q.line_count & 255) << 16) | ((uint32_t)q.qlen << 24) | ((uint32_t)q.q_overflow << 28);
-        s[(size_t)W_TIME * ws] = (uint32_t)q.time_ms;
-        s[(size_t)W_DROPCOMBO * ws] = ((uint32_t)q.drop_delay & 0xFFFF) | (q.combo_remaining << 16);
-        s[(size_t)W_DROP_TIME * ws] = (uint32_t)q.drop_time;
-        s[(size_t)W_SPEEDUP_TIME * ws] = (uint32_t)q.speedup_time;
-        s[(size_t)W_LOCK_TIME * ws] = (uint32_t)q.lock_time;
-        s[(size_t)W_COMBO_START * ws] = (uint32_t)q.combo_start;
-        s[(size_t)W_COMBO_TIME * ws] = (uint32_t)q.combo_time;
-        s[(size_t)W_INCOMING * ws] = f2u(q.incoming);
-        s[(size_t)W_MIN_REMAINING * ws] = (uint32_t)q.min_remaining;
-        s[(size_t)W_PIECE_DRAWS * ws] = q.piece_draws;
-        s[(size_t)W_HOLE_DRAWS * ws] = q.hole_draws;
-        s[(size_t)W_STATS0 * ws] = (q.lines_sent & 0xFFFF) | (q.lines_cleared << 16);
-        s[(size_t)W_STATS1 * ws] = (q.lines_blocked & 0xFFFF) | (q.max_combo << 16);
-        s[(size_t)W_STATS2 * ws] = (q.lines_seen & 0xFFFF) | (q.garbage_cleared << 16);
+                                  ((uint32_t)(q.reward & 255) << 19));
+        st_stream(&s[(size_t)W_MISC * ws], (uint32_t)(q.inc_count & 255) | ((uint32_t)(q.combo_count & 255) << 8) |
+                                 ((uint32_t)(q.line_count & 255) << 16) | ((uint32_t)q.qlen << 24) | ((uint32_t)q.q_overflow << 28));
+        st_stream(&s[(size_t)W_TIME * ws], (uint32_t)q.time_ms);
+        st_stream(&s[(size_t)W_DROPCOMBO * ws], ((uint32_t)q.drop_delay & 0xFFFF) | (q.combo_remaining << 16));
+        st_stream(&s[(size_t)W_DROP_TIME * ws], (uint32_t)q.drop_time);
+        st_stream(&s[(size_t)W_SPEEDUP_TIME * ws], (uint32_t)q.speedup_time);
+        st_stream(&s[(size_t)W_LOCK_TIME * ws], (uint32_t)q.lock_time);
+        st_stream(&s[(size_t)W_COMBO_START * ws], (uint32_t)q.combo_start);
+        st_stream(&s[(size_t)W_COMBO_TIME * ws], (uint32_t)q.combo_time);
+        st_stream(&s[(size_t)W_INCOMING * ws], f2u(q.incoming));
+        st_stream(&s[(size_t)W_MIN_REMAINING * ws], (uint32_t)q.min_remaining);
+        st_stream(&s[(size_t)W_PIECE_DRAWS * ws], q.piece_draws);
+        st_stream(&s[(size_t)W_HOLE_DRAWS * ws], q.hole_draws);
+        st_stream(&s[(size_t)W_STATS0 * ws], (q.lines_sent & 0xFFFF) | (q.lines_cleared << 16));
+        st_stream(&s[(size_t)W_STATS1 * ws], (q.lines_blocked & 0xFFFF) | (q.max_combo << 16));
+        st_stream(&s[(size_t)W_STATS2 * ws], (q.lines_seen & 0xFFFF) | (q.garbage_cleared << 16));
         if (q.q_loaded || q.qlen > 0) {
             for (int i = 0; i < FIFO_CAP / 2; i++)
-                s[(size_t)(W_FIFO_COUNT0 + i) * ws] = ((uint32_t)q.qcount[2 * i] & 0xFFFF) | ((uint32_t)q.qcount[2 * i + 1] << 16);
-            for (int i = 0; i < FIFO_CAP; i++) s[(size_t)(W_FIFO_DELAY0 + i) * ws] = (uint32_t)q.qdelay[i];
+                st_stream(&s[(size_t)(W_FIFO_COUNT0 + i) * ws], ((uint32_t)q.qcount[2 * i] & 0xFFFF) | ((uint32_t)q.qcount[2 * i + 1] << 16));
+            for (int i = 0; i < FIFO_CAP; i++) st_stream(&s[(size_t)(W_FIFO_DELAY0 + i) * ws], (uint32_t)q.qdelay[i]);
         }
     }
 }
@@ -291,7 +307,14 @@ TE_HD uint32_t table_byte(const Ctx& cx, uint32_t seed16, uint32_t draw, uint32_
     }
     uint32_t chunk = draw / (uint32_t)CHUNK;
     uint32_t r = draw - chunk * (uint32_t)CHUNK;
-    return cx.chunks[chunk][(size_t)seed16 * CHUNK + r];
+    return cx.table[((size_t)chunk * 65536u + seed16) * CHUNK + r];
+}
+
+// Issue the read of the next dealt piece early (right after the state load) so that its latency
+// hides under the key interpreter instead of sitting in front of the spawn test.
+TE_HD void prefetch_next(const Ctx& cx, Player& q, uint32_t seed16, uint32_t& status) {
+    q.pf_next = table_byte(cx, seed16, q.piece_draws, status);
+    q.pf_ok = 1;
 }
 
 // ---------------------------------------------------------------- garbage queue (Garbage.cpp)
@@ -395,7 +418,9 @@ TE_HD bool spawn_next(const Ctx& cx, Player& q, uint32_t seed16, uint32_t& statu
     q.rot = spawn_rot(q.kind);
     q.x = (NCOL - 4) / 2;
     q.y = 0;
-    q.next = (int)(table_byte(cx, seed16, q.piece_draws, status) & 7u);
+    uint32_t byte = q.pf_ok ? q.pf_next : table_byte(cx, seed16, q.piece_draws, status);
+    q.pf_ok = 0;
+    q.next = (int)(byte & 7u);
     q.piece_draws++;
     uint32_t shape = shape_of(cx, q.kind, q.rot);
     if (!fits_at(cx, q, shape, q.x, 0)) { stamp(q, shape); return true; }
@@ -423,6 +448,9 @@ TE_HD void lock_piece(const Ctx& cx, Player& q) {
 
 // gamePlay.cpp:54-59 hd_finish; -1 = died
 TE_HD int settle(const Ctx& cx, Player& q, uint32_t seed16, uint32_t& status) {
+#if defined(TE_ABLATE) && (TE_ABLATE & 8)
+    return 0;                                        // diagnostic build: no clear / spawn
+#endif
     int sent = score_clears(q, clear_rows(cx, q));
     if (spawn_next(cx, q, seed16, status)) return -1;
     return sent;
@@ -472,6 +500,9 @@ TE_HD bool push_garbage(const Ctx& cx, Player& q, uint32_t seed16, uint32_t& sta
 // gamePlay.cpp:90-114 delayCheck
 TE_HD int tick(const Ctx& cx, Player& q, int ms, uint32_t seed16, uint32_t& status) {
     q.time_ms += ms;
+#if defined(TE_ABLATE) && (TE_ABLATE & 4)
+    return 0;                                        // diagnostic build: no timers / garbage / combo
+#endif
     if (gravity_due(q, q.time_ms)) soft_drop(cx, q);
     if (q.lock_armed && q.time_ms > q.lock_time && !soft_drop(cx, q)) {    // DropDelay.cpp:43-48
         lock_piece(cx, q);                                                  // gamePlay.cpp:38-46 hd
@@ -492,7 +523,7 @@ TE_HD int tick(const Ctx& cx, Player& q, int ms, uint32_t seed16, uint32_t& stat
 
 // gamePlay.cpp:206-216 restartRound + :218-230 seed, through the RNG tables (tetris_tables.h).
 // Not reset (as in the reference): reward, inc_count, combo_remaining.
-TE_HD void restart_player(const Ctx& cx, Player& q, uint32_t seed16, uint32_t& status) {
+TE_HD void restart_player(const Ctx& cx, Player& q, uint32_t seed16, uint32_t& status, const ResetPrefetch* pf = nullptr) {
     for (int c = 0; c < NCOL; c++) q.col[c] = 0;
     q.qlen = 0; q.q_overflow = 0; q.lines_blocked = 0; q.min_remaining = 1000;
     for (int i = 0; i < FIFO_CAP; i++) { q.qcount[i] = 0; q.qdelay[i] = 0; }
@@ -500,9 +531,16 @@ TE_HD void restart_player(const Ctx& cx, Player& q, uint32_t seed16, uint32_t& s
     q.lines_sent = 0; q.lines_cleared = 0; q.garbage_cleared = 0;
     q.speedup_time = 0; q.drop_delay = 1000; q.drop_time = 0; q.lock_time = 0; q.lock_armed = 0;
     q.time_ms = 0; q.incoming = 0.0f; q.lines_seen = 0; q.dead = 0;
-    uint32_t j = cx.first_ok[seed16];
-    q.kind = (int)(table_byte(cx, seed16, j, status) & 7u);
-    q.next = (int)(table_byte(cx, seed16, j + 1, status) & 7u);
+    uint32_t j, b0, b1;
+    if (pf && pf->ok && pf->seed16 == seed16) { j = pf->first_ok; b0 = pf->b0; b1 = pf->b1; }
+    else {
+        j = cx.first_ok[seed16];
+        b0 = table_byte(cx, seed16, j, status);
+        b1 = table_byte(cx, seed16, j + 1, status);
+    }
+    q.kind = (int)(b0 & 7u);
+    q.next = (int)(b1 & 7u);
+    q.pf_ok = 0;
     q.rot = spawn_rot(q.kind);
     q.x = (NCOL - 4) / 2; q.y = 0;
     q.piece_draws = j + 2; q.hole_draws = 0;
@@ -510,7 +548,7 @@ TE_HD void restart_player(const Ctx& cx, Player& q, uint32_t seed16, uint32_t& s
 
 // PythonHandle.cpp:49-71 reset + seed
 template <int P>
-TE_HD void reset_game(const Ctx& cx, Game<P>& g, uint32_t seed16) {
+TE_HD void reset_game(const Ctx& cx, Game<P>& g, uint32_t seed16, const ResetPrefetch* pf = nullptr) {
     g.round_over = 0;
     int winner = -1, alive = 0;
     TE_UNROLL
@@ -521,7 +559,27 @@ TE_HD void reset_game(const Ctx& cx, Game<P>& g, uint32_t seed16) {
     if (alive > 1) g.last_winner = -1;
     g.seed16 = seed16 & 0xFFFFu;
     TE_UNROLL
-    for (int p = 0; p < P; p++) restart_player(cx, g.pl[p], g.seed16, g.status);
+    for (int p = 0; p < P; p++) restart_player(cx, g.pl[p], g.seed16, g.status, pf);
+}
+
+// A game can only end this step if some board already reaches into its top rows: a locked piece adds
+// at most 4 rows, a garbage push 1.  For those games fetch what reset_game will read (first_ok, then
+// the first two dealt pieces) while the step itself is still computing.  A miss of this predictor
+// only costs latency: reset_game falls back to reading the tables itself.
+template <int P>
+TE_HD void prefetch_reset(const Ctx& cx, const Game<P>& g, uint32_t next_seed16, ResetPrefetch& pf) {
+    uint32_t top = 0;
+    TE_UNROLL
+    for (int p = 0; p < P; p++)
+        for (int c = 0; c < NCOL; c++) top |= g.pl[p].col[c];
+    pf.ok = 0; pf.seed16 = next_seed16 & 0xFFFFu; pf.first_ok = 0; pf.b0 = 0; pf.b1 = 0;
+    if (top & 0x3FFu) {
+        uint32_t st = 0;
+        pf.first_ok = cx.first_ok[pf.seed16];
+        pf.b0 = table_byte(cx, pf.seed16, pf.first_ok, st);
+        pf.b1 = table_byte(cx, pf.seed16, pf.first_ok + 1, st);
+        pf.ok = 1;
+    }
 }
 
 // PythonHandle.cpp:5-25 init: fresh GamePlay objects (nextpiece 0, reward 0, ...), restartRound, seed
@@ -540,11 +598,12 @@ TE_HD void init_game(const Ctx& cx, Game<P>& g, uint32_t seed16) {
 
 // ---------------------------------------------------------------- key interpreter
 
-// gameField.cpp:55-103 rcw / rccw / r180 with the 7-offset kick test; turn = +1, +3 (ccw), +2
-TE_HD bool rotate_piece(const Ctx& cx, Player& q, int turn) {
+// gameField.cpp:55-103 rcw / rccw / r180 with the 7-offset kick test; turn = +1, +3 (ccw), +2.
+// `b0` must be band_window(q.y) on entry and is kept equal to band_window(q.y) on exit, so a run of
+// rotations and sideways moves at one height shares a single window.
+TE_HD bool rotate_piece_band(const Ctx& cx, Player& q, int turn, uint64_t& b0) {
     int nr = (q.rot + turn) & 3;
     uint32_t shape = shape_of(cx, q.kind, nr);
-    uint64_t b0 = band_window(cx, q, q.y);
     if (fits_band(b0, shape, q.x)) { q.rot = nr; return true; }
     uint64_t b1 = band_window(cx, q, q.y + 1);
     // (dx,dy) in the reference's order: (0,+1) (-1,0) (+1,0) (-1,+1) (+1,+1) (-2,0) (+2,0)
@@ -558,7 +617,13 @@ TE_HD bool rotate_piece(const Ctx& cx, Player& q, int turn) {
     else if (fits_band(b0, shape, q.x + 2)) { dx = 2; }
     if (dx == 99) return false;
     q.rot = nr; q.x += dx; q.y += dy;
+    if (dy) b0 = b1;
     return true;
+}
+
+TE_HD bool rotate_piece(const Ctx& cx, Player& q, int turn) {
+    uint64_t b0 = band_window(cx, q, q.y);
+    return rotate_piece_band(cx, q, turn, b0);
 }
 
 // PythonHandle.cpp:73-112 action_make
@@ -584,18 +649,68 @@ TE_HD void press_key(const Ctx& cx, Player& q, int key) {
     }
 }
 
-// sventon_utils.py:9-13: [8]*r + [2] + [3]*t + [7], phase-aligned across lanes
+// all four rotations of one piece kind in one 128-bit LDS read (table rows are 16-byte aligned)
+struct Shapes4 { uint32_t r[4]; };
+TE_HD Shapes4 shapes_of_kind(const Ctx& cx, int kind) {
+    Shapes4 out;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint4 v = *reinterpret_cast<const uint4*>(cx.shapes + ((kind & 7) << 2));
+    out.r[0] = v.x; out.r[1] = v.y; out.r[2] = v.z; out.r[3] = v.w;
+#else
+    for (int i = 0; i < 4; i++) out.r[i] = cx.shapes[((kind & 7) << 2) | i];
+#endif
+    return out;
+}
+TE_HD uint32_t pick4(const Shapes4& s, int rot) {
+    uint32_t lo = (rot & 1) ? s.r[1] : s.r[0];
+    uint32_t hi = (rot & 1) ? s.r[3] : s.r[2];
+    return (rot & 2) ? hi : lo;
+}
+
+// bit xs of the result = 1  <=>  the shape fits at x = xs - 2 (xs = 0..12) in this band window
+TE_HD uint32_t free_positions(uint64_t band, uint32_t shape) {
+    const uint64_t pc = (uint64_t)(shape & 0xFFFFu);
+    uint32_t free = 0;
+    for (int xs = 0; xs <= 12; xs++) free |= (((pc << (4 * xs)) & band) == 0 ? 1u : 0u) << xs;
+    return free;
+}
+
+// sventon_utils.py:9-13: the key list [8]*r + [2] + [3]*t + [7] executed literally
+// (PythonHandle.cpp:73-112), but without per-lane loops:
+//  * rotations: when the next r raw rotations all fit in place, none of them kicks and the result is
+//    rot + r; only lanes where some intermediate rotation collides walk the kick sequence.
+//  * key 2 then t x key 3: with the set F of free x positions at this height, "left until blocked"
+//    ends just right of the nearest blocked position on the left, and each of the t single steps right
+//    succeeds until the first blocked position on the right (a blocked step stays blocked).
 TE_HD void play_rt(const Ctx& cx, Player& q, int r, int t) {
-    for (int i = 0; i < 3; i++)
-        if (i < r) rotate_piece(cx, q, 1);
-    uint32_t shape = shape_of(cx, q.kind, q.rot);
+#if defined(TE_ABLATE) && (TE_ABLATE & 2)
+    lock_piece(cx, q); return;                       // diagnostic build: no rotations / slides
+#endif
+    const Shapes4 sh = shapes_of_kind(cx, q.kind);
     uint64_t band = band_window(cx, q, q.y);
-    while (fits_band(band, shape, q.x - 1)) q.x--;
-    for (int i = 0; i < t; i++) {
-        if (!fits_band(band, shape, q.x + 1)) break;   // a blocked single step stays blocked
-        q.x++;
+    bool fit1 = fits_band(band, pick4(sh, q.rot + 1), q.x);
+    bool fit2 = fits_band(band, pick4(sh, q.rot + 2), q.x);
+    bool fit3 = fits_band(band, pick4(sh, q.rot + 3), q.x);
+    bool easy = (r < 1 || fit1) && (r < 2 || fit2) && (r < 3 || fit3);
+    if (easy) {
+        q.rot = (q.rot + r) & 3;
+    } else {
+        for (int i = 0; i < 3; i++)
+            if (i < r) rotate_piece_band(cx, q, 1, band);
     }
-    lock_piece(cx, q);
+    const uint32_t shape = pick4(sh, q.rot);
+    const uint32_t free = free_positions(band, shape);
+    const int xs0 = q.x + 2;
+    const uint32_t blocked_left = ~free & ((1u << xs0) - 1u);
+    int xs = blocked_left ? 32 - clz32(blocked_left) : 0;
+    const uint32_t blocked_right = (~free >> (xs + 1)) | (1u << 13);
+    xs += imin(t, ctz32(blocked_right));
+    q.x = xs - 2;
+    // gamePlay.cpp:48-52 hd_make
+    q.y += drop_distance(cx, q, shape);
+    stamp(q, shape);
+    q.drop_time = q.time_ms;
+    q.lock_armed = 0;
 }
 
 // ---------------------------------------------------------------- the two-phase step

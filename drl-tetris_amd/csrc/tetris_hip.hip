@@ -24,12 +24,15 @@ __device__ const ShapeTable d_shape_table = make_shape_table();
 
 template <int P, int MODE>
 __global__ __launch_bounds__(256) void k_game(KArgs a) {
-    __shared__ uint32_t s_shapes[32];
-    if (threadIdx.x < 32) s_shapes[threadIdx.x] = d_shape_table.s[threadIdx.x];
-    __syncthreads();
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ __attribute__((aligned(16))) uint32_t s_shapes[32];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool active = i < a.n;
     LaneCounters cnt = {0, 0, 0, 0};
-    if (i < a.n) game_body<P, MODE>(a, i, s_shapes, cnt);
+    Game<P> g;
+    if (active) game_load<P, MODE>(a, i, g);          // state loads in flight ...
+    if (threadIdx.x < 32) s_shapes[threadIdx.x] = d_shape_table.s[threadIdx.x];
+    __syncthreads();                                   // ... while the shape table lands in LDS
+    if (active) game_run<P, MODE>(a, i, s_shapes, g, cnt);
     if (MODE == M_ROLLOUT) {
         // Counters without atomics: wave reduction (DPP/shuffle), 4 waves through LDS, then the
         // workgroup adds into ITS OWN slot counters[blockIdx.x][4] (launches on one stream are
@@ -117,24 +120,33 @@ struct Tables {
     float* d_w = nullptr;            // [7][65536]
     uint8_t* d_first_ok = nullptr;   // [65536]
     double* d_pow = nullptr;         // [256]
-    std::vector<uint8_t*> chunks;    // device pointers, 65536*624 bytes each
-    const uint8_t** d_chunks = nullptr;   // device array [MAX_CHUNKS]
+    uint8_t* d_table = nullptr;      // [(chunk * 65536 + seed) * 624 + r], capacity `cap_chunks`
+    int n_chunks = 0, cap_chunks = 0;
+    std::vector<uint8_t*> retired;   // outgrown tables: other streams may still be reading them
 };
+static const size_t CHUNK_BYTES = (size_t)65536 * CHUNK;
 static std::mutex g_tab_mutex;
 static std::vector<Tables*> g_tables;
 
 static int tables_extend(Tables* t, hipStream_t stream) {
-    if ((int)t->chunks.size() >= MAX_CHUNKS) return fail(TETRIS_E_STREAM, "RNG tables: MAX_CHUNKS reached");
-    uint8_t* d = nullptr;
-    HIP_TRY(hipMalloc((void**)&d, (size_t)65536 * CHUNK));
+    if (t->n_chunks >= MAX_CHUNKS) return fail(TETRIS_E_STREAM, "RNG tables: MAX_CHUNKS reached");
+    if (t->n_chunks == t->cap_chunks) {            // grow: new allocation, copy, retire the old one
+        int cap = t->cap_chunks ? t->cap_chunks * 2 : 2;
+        if (cap > MAX_CHUNKS) cap = MAX_CHUNKS;
+        uint8_t* d = nullptr;
+        HIP_TRY(hipMalloc((void**)&d, CHUNK_BYTES * cap));
+        if (t->n_chunks) HIP_TRY(hipMemcpyAsync(d, t->d_table, CHUNK_BYTES * t->n_chunks, hipMemcpyDeviceToDevice, stream));
+        if (t->d_table) t->retired.push_back(t->d_table);
+        t->d_table = d;
+        t->cap_chunks = cap;
+    }
     MapArg m;
     memcpy(m.m, t->map, 8);
-    int c = (int)t->chunks.size();
-    hipLaunchKernelGGL(k_gen_chunk, dim3(256), dim3(256), 0, stream, t->d_mt, t->d_w, d, t->d_first_ok, c, m, t->only_sz);
+    hipLaunchKernelGGL(k_gen_chunk, dim3(256), dim3(256), 0, stream, t->d_mt, t->d_w, t->d_table + CHUNK_BYTES * t->n_chunks,
+                       t->d_first_ok, t->n_chunks, m, t->only_sz);
     HIP_TRY(hipGetLastError());
-    t->chunks.push_back(d);
-    HIP_TRY(hipMemcpyAsync((void*)(t->d_chunks + c), &t->chunks[c], sizeof(uint8_t*), hipMemcpyHostToDevice, stream));
     HIP_TRY(hipStreamSynchronize(stream));
+    t->n_chunks++;
     return TETRIS_OK;
 }
 
@@ -152,8 +164,6 @@ static int tables_acquire(Tables** out, int device, const uint8_t map[7], hipStr
     HIP_TRY(hipMalloc((void**)&t->d_w, (size_t)7 * 65536 * 4));
     HIP_TRY(hipMalloc((void**)&t->d_first_ok, 65536));
     HIP_TRY(hipMalloc((void**)&t->d_pow, 256 * sizeof(double)));
-    HIP_TRY(hipMalloc((void**)&t->d_chunks, MAX_CHUNKS * sizeof(uint8_t*)));
-    HIP_TRY(hipMemsetAsync((void*)t->d_chunks, 0, MAX_CHUNKS * sizeof(uint8_t*), stream));
     double powtab[256];
     for (int c = 0; c < 256; c++) powtab[c] = pow((double)c, 1.4 + (double)c * 0.01);   // Combo.cpp:41, host libm
     HIP_TRY(hipMemcpyAsync(t->d_pow, powtab, sizeof powtab, hipMemcpyHostToDevice, stream));
@@ -176,8 +186,8 @@ static void tables_release(Tables* t) {
     for (size_t i = 0; i < g_tables.size(); i++)
         if (g_tables[i] == t) { g_tables.erase(g_tables.begin() + i); break; }
     (void)hipFree(t->d_mt); (void)hipFree(t->d_w); (void)hipFree(t->d_first_ok); (void)hipFree(t->d_pow);
-    for (uint8_t* c : t->chunks) (void)hipFree(c);
-    (void)hipFree((void*)t->d_chunks);
+    (void)hipFree(t->d_table);
+    for (uint8_t* c : t->retired) (void)hipFree(c);
     delete t;
 }
 
@@ -224,8 +234,8 @@ static KArgs base_args(tetris_batch* b, int n, const int32_t* d_idx) {
     KArgs a;
     memset(&a, 0, sizeof a);
     a.state = b->d_state; a.gstate = b->d_gstate; a.status = b->d_status;
-    a.chunks = (const uint8_t* const*)b->tab->d_chunks; a.first_ok = b->tab->d_first_ok; a.combo_pow = b->tab->d_pow;
-    a.n_draws = (uint32_t)b->tab->chunks.size() * CHUNK; a.margin = b->margin;
+    a.table = b->tab->d_table; a.first_ok = b->tab->d_first_ok; a.combo_pow = b->tab->d_pow;
+    a.n_draws = (uint32_t)b->tab->n_chunks * CHUNK; a.margin = b->margin;
     a.H = b->H; a.n_games = b->N; a.n = n; a.idx = d_idx; a.game_offset = b->game_offset;
     return a;
 }
@@ -299,7 +309,7 @@ int tetris_device_count(void) {
 int tetris_record_size(void) { return (int)sizeof(tetris_record); }
 int tetris_layout_words(void) { return NWORDS; }
 int tetris_snapshot_words(const tetris_batch* b) { return b ? NGWORDS + b->P * NWORDS : 0; }
-int tetris_table_chunks(const tetris_batch* b) { return b && b->tab ? (int)b->tab->chunks.size() : 0; }
+int tetris_table_chunks(const tetris_batch* b) { return b && b->tab ? b->tab->n_chunks : 0; }
 void* tetris_device_state(tetris_batch* b) { return b ? b->d_state : nullptr; }
 void* tetris_stream(tetris_batch* b) { return b ? (void*)b->stream : nullptr; }
 
@@ -606,12 +616,12 @@ int tetris_rollout_random(tetris_batch* b, int launches, int steps_per_launch, u
                           int ms, uint64_t counters[4], float* elapsed_ms) {
     int rc = check_batch(b);
     if (rc) return rc;
-    if (launches < 1 || steps_per_launch < 1) return fail(TETRIS_E_ARG, "launches/steps_per_launch must be >= 1");
+    if (launches < 1 || steps_per_launch < 0) return fail(TETRIS_E_ARG, "launches must be >= 1, steps_per_launch >= 0");
     // A launch may consume 2 piece draws per step and player, and the host only looks at the status
     // word between groups of launches: keep each group <= 256 env-steps and the low-water margin
     // above what one group can consume, so the tables are always extended in time.
     if (steps_per_launch > 256) return fail(TETRIS_E_ARG, "steps_per_launch must be <= 256");
-    const int group = 256 / steps_per_launch;
+    const int group = steps_per_launch ? 256 / steps_per_launch : 256;   // 0 = load/store only (diagnostic floor)
     const uint32_t saved_margin = b->margin;
     b->margin = (uint32_t)(2 * group * steps_per_launch + 16);
     if (b->margin < saved_margin) b->margin = saved_margin;

@@ -14,7 +14,7 @@ struct KArgs {
     uint32_t* state;
     uint32_t* gstate;
     uint32_t* status;
-    const uint8_t* const* chunks;
+    const uint8_t* table;     // [(chunk * 65536 + seed16) * 624 + r]
     const uint8_t* first_ok;
     const double* combo_pow;
     uint32_t n_draws, margin;
@@ -47,7 +47,7 @@ struct LaneCounters { unsigned long long steps, episodes, lines, sent; };
 TE_HD Ctx make_ctx(const KArgs& a, const uint32_t* shapes) {
     Ctx cx;
     cx.shapes = shapes;
-    cx.chunks = a.chunks;
+    cx.table = a.table;
     cx.first_ok = a.first_ok;
     cx.combo_pow = a.combo_pow;
     cx.n_draws = a.n_draws;
@@ -89,29 +89,39 @@ TE_HD void make_rt(const Ctx& cx, Game<P>& g, int player, int r, int t) {
         if (p == player && !g.pl[p].dead) play_rt(cx, g.pl[p], r, t);
 }
 
+// Phase 1 of a lane's work: issue the state loads (nothing here needs the LDS shape table, so the
+// kernel runs this BEFORE its table-init barrier and both memory round-trips overlap).
 template <int P, int MODE>
-TE_HD void game_body(const KArgs& a, int i, const uint32_t* shapes, LaneCounters& cnt) {
+TE_HD void game_load(const KArgs& a, int i, Game<P>& g) {
+    const size_t slot = a.idx ? (size_t)a.idx[i] : (size_t)i;
+    if (MODE != M_INIT) load_game<P>(a.state, a.gstate, (size_t)a.n_games, slot, g);
+}
+
+// Phase 2: step and store.
+template <int P, int MODE>
+TE_HD void game_run(const KArgs& a, int i, const uint32_t* shapes, Game<P>& g, LaneCounters& cnt) {
     const size_t N = (size_t)a.n_games;
     const size_t slot = a.idx ? (size_t)a.idx[i] : (size_t)i;
     Ctx cx = make_ctx(a, shapes);
-    Game<P> g;
-    if (MODE == M_INIT) {
-        init_game<P>(cx, g, (uint32_t)(a.seeds ? (uint16_t)a.seeds[i] : 0));
-    } else {
-        load_game<P>(a.state, a.gstate, N, slot, g);
-    }
+    if (MODE == M_INIT) init_game<P>(cx, g, (uint32_t)(a.seeds ? (uint16_t)a.seeds[i] : 0));
     if (MODE == M_RESET) {
         reset_game<P>(cx, g, (uint32_t)(a.seeds ? (uint16_t)a.seeds[i] : 0));
     } else if (MODE == M_MAKE) {
         make_keys<P>(cx, a, i, g);
     } else if (MODE == M_FINISH) {
+        TE_UNROLL
+        for (int p = 0; p < P; p++) prefetch_next(cx, g.pl[p], g.seed16, g.status);
         int done = finish_game<P>(cx, g, a.ms);
         write_outputs<P>(a, i, g, done);
     } else if (MODE == M_STEP_KEYS) {
+        TE_UNROLL
+        for (int p = 0; p < P; p++) prefetch_next(cx, g.pl[p], g.seed16, g.status);
         make_keys<P>(cx, a, i, g);
         int done = finish_game<P>(cx, g, a.ms);
         write_outputs<P>(a, i, g, done);
     } else if (MODE == M_STEP_RT) {
+        TE_UNROLL
+        for (int p = 0; p < P; p++) prefetch_next(cx, g.pl[p], g.seed16, g.status);
         make_rt<P>(cx, g, a.player ? a.player[i] : 0, a.rot[i] & 3, a.trans[i]);
         int done = finish_game<P>(cx, g, a.ms);
         write_outputs<P>(a, i, g, done);
@@ -119,8 +129,16 @@ TE_HD void game_body(const KArgs& a, int i, const uint32_t* shapes, LaneCounters
         // SURVEY.md §8(d) synthetic workload: worker.py:91-118 with a counter-based random policy
         for (int s = 0; s < a.steps; s++) {
             unsigned long long step = a.first_step + (unsigned long long)s;
+            TE_UNROLL
+            for (int p = 0; p < P; p++) prefetch_next(cx, g.pl[p], g.seed16, g.status);
+            ResetPrefetch rpf;
+            prefetch_reset<P>(cx, g, episode_seed(a.game_offset + (uint32_t)slot, g.episode + 1), rpf);
             uint32_t w[4];
+#if defined(TE_ABLATE) && (TE_ABLATE & 1)
+            w[0] = (uint32_t)slot + (uint32_t)step; w[1] = (uint32_t)slot * 7u + (uint32_t)step;   // diagnostic build: no Philox
+#else
             philox4x32_10(a.policy_seed, a.game_offset + (uint32_t)slot, (uint32_t)step, (uint32_t)(step >> 32), w);
+#endif
             int r = (int)(w[0] & 3u), t = (int)(w[1] % 10u);
             int player = P > 1 ? (int)(step % (unsigned long long)P) : 0;
             uint32_t sent_before = 0;
@@ -136,10 +154,13 @@ TE_HD void game_body(const KArgs& a, int i, const uint32_t* shapes, LaneCounters
                 if (!g.pl[p].dead) cnt.lines += (unsigned)g.pl[p].reward;
             }
             cnt.sent += (sent_after - sent_before) & 0xFFFFu;
+#if defined(TE_ABLATE) && (TE_ABLATE & 16)
+            done = 0;                                // diagnostic build: no auto-reset
+#endif
             if (done) {
                 cnt.episodes++;
                 g.episode++;
-                reset_game<P>(cx, g, episode_seed(a.game_offset + (uint32_t)slot, g.episode));
+                reset_game<P>(cx, g, episode_seed(a.game_offset + (uint32_t)slot, g.episode), &rpf);
             }
         }
     }
@@ -151,6 +172,13 @@ TE_HD void game_body(const KArgs& a, int i, const uint32_t* shapes, LaneCounters
         *a.status |= g.status;
 #endif
     }
+}
+
+template <int P, int MODE>
+TE_HD void game_body(const KArgs& a, int i, const uint32_t* shapes, LaneCounters& cnt) {
+    Game<P> g;
+    game_load<P, MODE>(a, i, g);
+    game_run<P, MODE>(a, i, shapes, g, cnt);
 }
 
 // State views / __getstate__ (PythonHandle.h:54-82,123-308) of one game -> P records

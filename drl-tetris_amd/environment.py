@@ -1,0 +1,262 @@
+"""`tetris_environment_vector` — the drop-in for the reference's worker rollout loop
+(drl_tetris/worker.py:91-118), same method names and argument conventions as
+environment/tetris_environment_vector.py:9-191, but ONE batched GPU environment underneath instead
+of a Python list of single-game C++ handles.
+
+    env = tetris_environment_vector(n_envs, settings={...})
+    state        = env.get_state()                         # list of `state`
+    reward, done = env.perform_action(actions, player=p)   # lists
+    env.reset(env=[i for i, d in enumerate(done) if d])
+
+Index conventions follow tools/utils.py:10-31 `parse_arg`: `None` = all, list/ndarray = subset,
+int = broadcast.  Where the reference's vector class is broken (calls with missing arguments or
+undefined names: tetris_environment_vector.py:65,91,95,112,160) the evident intent is
+implemented.  Seeds: the reference seeds from time(NULL) (PythonHandle.cpp:68-71); here
+`settings["seed_source"]` (a callable -> int, default wall clock seconds) is asked once per reset call.
+"""
+import time
+
+import numpy as np
+
+from . import data_types, state_processors
+from .capi import TetrisBatch
+from .data_types import action, action_list, maingoal_reward, null_action, state
+
+DEFAULT_SETTINGS = {          # the env-relevant keys of experiments/presets.py:123-182
+    "game_size": [22, 10],
+    "pieces": [0, 1, 2, 3, 4, 5, 6],
+    "n_players": 2,
+    "time_elapsed_each_action": 400,
+    "action_type": "place_block",
+    "bar_null_moves": True,
+    "state_processor": "state_dict",
+    "old_state_dict": False,
+    "state_processor_separate_piece": True,
+    "augment_data": False,
+    "extra_rewards": False,
+    "reward_ammount": (1.0, 0.0),
+    "render": False,
+    "render_simulation": False,
+    "seed_source": None,
+    "device": 0,
+}
+
+
+def parse_arg(entry_idx, data, fill_up=None, indices=False):
+    """tools/utils.py:10-31"""
+    if entry_idx is None:
+        ret = data if type(data) is list else list(data)
+        idx = list(range(len(data)))
+    elif type(entry_idx) in (list, np.ndarray):
+        ret = [data[i] for i in entry_idx]
+        idx = entry_idx
+    else:
+        idx = [entry_idx] if fill_up is None else [entry_idx for _ in range(fill_up)]
+        ret = [data[i] for i in idx]
+    return (idx, ret) if indices else ret
+
+
+class tetris_environment_vector:
+    def __init__(self, n_envs, env_type=None, init_envs=None, settings=None, _lib_path=None):
+        s = dict(DEFAULT_SETTINGS)
+        s.update(settings or {})
+        s["game_area"] = s["game_size"][0] * s["game_size"][1]      # tools/utils.py:44
+        self.settings = s
+        assert s["action_type"] in ("place_block", "press_key")
+        self.n_envs = n_envs
+        self.env_type = env_type
+        self.n_players = s["n_players"]
+        self.player_idxs = list(range(self.n_players))
+        self.height, self.width = s["game_size"]
+        self._lib_path = _lib_path
+        if type(s["state_processor"]) is str:
+            func, names = state_processors.func_dict[s["state_processor"]]
+            self.state_processor = state_processors.state_processor(func, [s[k] for k in names])
+        else:
+            self.state_processor = state_processors.state_processor(s["state_processor"])
+        self._seed_source = s["seed_source"] or (lambda: int(time.time()))
+        seed = self._seed_source()
+        self.backend = TetrisBatch(n_envs, self.n_players, self.height, self.width, pieces=s["pieces"], seeds=seed,
+                                   device=s["device"], lib_path=_lib_path)
+        self._env_ids = list(range(n_envs))
+        self.done = np.zeros(n_envs, bool)
+        self.rounds_played = np.zeros(n_envs, np.int64)
+        self.round_reward = [[self._zero_reward() for _ in self.player_idxs] for _ in range(n_envs)]
+        self.tot_reward = [[self._zero_reward() for _ in self.player_idxs] for _ in range(n_envs)]
+        self.last_reward = [[None for _ in self.player_idxs] for _ in range(n_envs)]
+        if init_envs is None or (type(init_envs) is list and all(e is None for e in init_envs)):
+            self.reset()                       # "upon agreement with backend, we always reset once" (tetris_environment.py:40-41)
+        else:
+            self.set(init_envs)
+
+    # ------------------------------------------------------------------ helpers
+    def _zero_reward(self):
+        return maingoal_reward([0])
+
+    def _idx(self, env):
+        return np.asarray(parse_arg(env, self._env_ids), dtype=np.int32)
+
+    def _players(self, player, n):
+        return [int(p) for p in parse_arg(player, self.player_idxs, fill_up=n)]
+
+    def _reward(self, done, dead, player):
+        """tetris_environment.reward_fcn (tetris_environment.py:135-149)"""
+        base = 0
+        if done:
+            medead = int(dead[player])
+            youdead = int(dead[1 - player]) if self.n_players > 1 else 0
+            base = youdead - medead
+            if medead and youdead:
+                base = -1
+        return base
+
+    def _pack(self, actions, players, n):
+        K = max(1, max(len(a) for a in actions))
+        keys = np.zeros((n, self.n_players, K), np.uint8)
+        lens = np.ones((n, self.n_players), np.uint8)          # the other players get the null action [0]
+        for i, (a, p) in enumerate(zip(actions, players)):
+            assert type(a) is action, f"perform_action(action a, int p) was called with type(action)={type(a)}"
+            keys[i, p, : len(a)] = a
+            lens[i, p] = len(a)
+        return keys, lens
+
+    # ------------------------------------------------------------------ env interface
+    def reset(self, env=None):
+        idx = self._idx(env)
+        if len(idx) == 0:
+            return []
+        self.backend.reset(idx, seeds=self._seed_source())
+        self.done[idx] = False
+        for i in idx:
+            self.rounds_played[i] += 1
+            self.round_reward[i] = [self._zero_reward() for _ in self.player_idxs]
+        return [None for _ in idx]
+
+    def perform_action(self, actions, env=None, player=None):
+        idx = self._idx(env)
+        n = len(idx)
+        players = self._players(player, n)
+        actions = list(actions)
+        assert len(actions) == n and len(players) == n
+        keys, lens = self._pack(actions, players, n)
+        done, _lines, dead = self.backend.step_keys(keys, lens, ms=self.settings["time_elapsed_each_action"], idx=idx)
+        rewards, dones = [None] * n, [None] * n
+        for j, (i, p) in enumerate(zip(idx, players)):
+            self.done[i] = bool(done[j])
+            r = maingoal_reward([self._reward(done[j], dead[j], p)])
+            self.last_reward[i][p] = r
+            self.round_reward[i][p] = self.round_reward[i][p] + r
+            self.tot_reward[i][p] = self.tot_reward[i][p] + r
+            rewards[j], dones[j] = r, bool(done[j])
+        return rewards, dones
+
+    def get_state(self, env=None):
+        idx = self._idx(env)
+        blobs = self.backend.snapshot(idx)
+        rec, ro, lw = self.backend.observe(idx)
+        return [state(data_types.backend_snapshot(blobs[j], rec[j], self.height, self.width, ro[j], lw[j]), self.state_processor)
+                for j in range(len(idx))]
+
+    def set(self, target, env=None):
+        """Restore games from state / backend_snapshot / another vector env (tetris_environment.py:168-176)."""
+        idx = self._idx(env)
+        if isinstance(target, tetris_environment_vector):
+            src = target.backend.snapshot(np.arange(len(idx), dtype=np.int32) if env is None else idx)
+            self.backend.restore(src, idx)
+            return [None for _ in idx]
+        targets = target if type(target) is list else [target for _ in idx]
+        blobs = np.zeros((len(idx), self.backend.snapshot_words), np.uint32)
+        for j, t in enumerate(targets):
+            b = t.backend_state if isinstance(t, state) else t
+            if not isinstance(b, data_types.backend_snapshot):
+                raise TypeError(f"cannot set an environment from {type(t)}")
+            b.sync_dead_to_blob()
+            blobs[j] = b.blob
+        self.backend.restore(blobs, idx)
+        self.done[idx] = [bool(t.backend_state.round_over if isinstance(t, state) else t.round_over) for t in targets]
+        return [None for _ in idx]
+
+    def simulate_actions(self, actions, env=None, player=None, finalize=True):
+        """Per env: the states reached by each action of its action_list from the CURRENT state, which is
+        left untouched (tetris_environment.simulate_actions, tetris_environment.py:87-100).  All
+        (env, action) pairs are stepped in one scratch batch."""
+        idx = self._idx(env)
+        players = self._players(player, len(idx))
+        counts = [len(a) for a in actions]
+        total = sum(counts)
+        if total == 0:
+            return [[] for _ in idx]
+        anchors = self.backend.snapshot(idx)
+        scratch = TetrisBatch(total, self.n_players, self.height, self.width, pieces=self.settings["pieces"], seeds=0,
+                              device=self.settings["device"], lib_path=self._lib_path)
+        scratch.restore(np.repeat(anchors, counts, axis=0))
+        flat_actions = [a if type(a) is action else action(a) for al in actions for a in al]
+        flat_players = [p for p, c in zip(players, counts) for _ in range(c)]
+        keys, lens = self._pack(flat_actions, flat_players, total)
+        if finalize:
+            scratch.step_keys(keys, lens, ms=self.settings["time_elapsed_each_action"])
+        else:
+            scratch.make_actions(keys, lens)
+        blobs = scratch.snapshot()
+        rec, ro, lw = scratch.observe()
+        scratch.close()
+        out, k = [], 0
+        for c in counts:
+            out.append([state(data_types.backend_snapshot(blobs[k + j], rec[k + j], self.height, self.width, ro[k + j], lw[k + j]),
+                              self.state_processor) for j in range(c)])
+            k += c
+        return out
+
+    def get_actions(self, env=None, player=None):
+        idx = self._idx(env)
+        players = self._players(player, len(idx))
+        assert len(idx) == len(players), "You want to specify one player per tetris_environment that the tetris_environment_vector manages"
+        if self.settings["action_type"] == "press_key":
+            return [action_list([[k] for k in range(11)]) for _ in idx]      # tetris_environment.py:85-86
+        lists = self.backend.get_actions(idx, players)
+        return [action_list(l, remove_null=self.settings["bar_null_moves"]) for l in lists]
+
+    def get_random_action(self, env=None, player=None):
+        lists = self.get_actions(env=env, player=player)
+        return [al[np.random.randint(low=0, high=len(al))] for al in lists]
+
+    def simulate_all_actions(self, env=None, player=None, finalize=True):
+        return self.simulate_actions(self.get_actions(env=env, player=player), env=env, player=player, finalize=finalize)
+
+    def get_winner(self, env=None, player=None):
+        idx = self._idx(env)
+        rec, ro, _ = self.backend.observe(idx)
+        out = []
+        for j in range(len(idx)):
+            if not ro[j]:
+                out.append(None)
+                continue
+            alive = [p for p in self.player_idxs if not rec[j, p]["dead"]]
+            out.append(alive[0] if alive else 666)        # tetris_environment.py:118-125
+        return out
+
+    def get_info(self, env=None):
+        idx = self._idx(env)
+        rec, _, _ = self.backend.observe(idx)
+        return [{"is_dead": [rec[j, p]["dead"] for p in self.player_idxs], "reward": self.last_reward[i],
+                 "tot_reward": self.tot_reward[i], "round_reward": self.round_reward[i],
+                 "rounds_played": int(self.rounds_played[i])} for j, i in enumerate(idx)]
+
+    def get_fields(self, env=None):
+        rec, _, _ = self.backend.observe(self._idx(env))
+        return [[rec[j, p]["field"][: self.height, : self.width] for p in self.player_idxs] for j in range(len(rec))]
+
+    def render(self, env=None):
+        return None       # visualisation (env_utils/draw_tetris.py) is out of scope; kept as a no-op hook
+
+    def copy(self):
+        return tetris_environment_vector(self.n_envs, self.env_type, init_envs=self, settings=self.settings, _lib_path=self._lib_path)
+
+    def generate_pieces(self, env=None):
+        p = self.settings["pieces"]
+        return [(p * 7)[:7] for _ in self._idx(env)]
+
+    def __str__(self, env=None):
+        width = max(len(k) for k in self.settings)
+        body = "".join("\t{:{}}\t{}\n".format(k, width, v) for k, v in self.settings.items())
+        return "<tetris_vector_env>" + "".join("tetris_environment settings:\n" + body for _ in self._idx(env)) + "</tetris_vector_env>"

@@ -28,20 +28,19 @@ struct Tables {
     std::vector<float> w;            // [7][65536]
     std::vector<uint8_t> first_ok;   // [65536]
     double powtab[256];
-    std::vector<std::vector<uint8_t>> chunks;
-    std::vector<const uint8_t*> chunk_ptrs;
+    std::vector<uint8_t> table;      // [(chunk * 65536 + seed) * 624 + r]
+    int n_chunks = 0;
     void extend() {
-        int c = (int)chunks.size();
-        chunks.emplace_back((size_t)65536 * CHUNK);
-        uint8_t* out = chunks.back().data();
+        int c = n_chunks;
+        table.resize((size_t)65536 * CHUNK * (c + 1));
+        uint8_t* out = table.data() + (size_t)65536 * CHUNK * c;
 #pragma omp parallel for schedule(static)
         for (int seed = 0; seed < 65536; seed++) {
             uint8_t fo = 0;
             gen_chunk_for_seed(mt.data() + seed, 65536, w.data() + seed, 65536, out + (size_t)seed * CHUNK, &fo, c, map, only_sz != 0);
             if (c == 0) first_ok[seed] = fo;
         }
-        chunk_ptrs.assign(MAX_CHUNKS, nullptr);
-        for (size_t i = 0; i < chunks.size(); i++) chunk_ptrs[i] = chunks[i].data();
+        n_chunks++;
     }
 };
 static std::map<std::string, Tables*> g_tables;
@@ -79,8 +78,8 @@ static KArgs base_args(tetris_batch* b, int n, const int32_t* idx) {
     KArgs a;
     memset(&a, 0, sizeof a);
     a.state = b->state.data(); a.gstate = b->gstate.data(); a.status = &b->status;
-    a.chunks = b->tab->chunk_ptrs.data(); a.first_ok = b->tab->first_ok.data(); a.combo_pow = b->tab->powtab;
-    a.n_draws = (uint32_t)b->tab->chunks.size() * CHUNK; a.margin = b->margin;
+    a.table = b->tab->table.data(); a.first_ok = b->tab->first_ok.data(); a.combo_pow = b->tab->powtab;
+    a.n_draws = (uint32_t)b->tab->n_chunks * CHUNK; a.margin = b->margin;
     a.H = b->H; a.n_games = b->N; a.n = n; a.idx = idx; a.game_offset = b->game_offset;
     return a;
 }
@@ -102,7 +101,7 @@ static int finish_call(tetris_batch* b) {
     if (st & ST_STREAM_EXHAUSTED) return fail(TETRIS_E_STREAM, "an episode ran past the RNG tables");
     if (st & ST_FIFO_OVERFLOW) return fail(TETRIS_E_FIFO, "garbage FIFO overflow");
     if (st & ST_NEED_EXTEND) {
-        if ((int)b->tab->chunks.size() >= MAX_CHUNKS) return fail(TETRIS_E_STREAM, "MAX_CHUNKS reached");
+        if (b->tab->n_chunks >= MAX_CHUNKS) return fail(TETRIS_E_STREAM, "MAX_CHUNKS reached");
         b->tab->extend();
         b->status = 0;
     }
@@ -146,7 +145,7 @@ int tetris_device_count(void) { return 0; }
 int tetris_record_size(void) { return (int)sizeof(tetris_record); }
 int tetris_layout_words(void) { return NWORDS; }
 int tetris_snapshot_words(const tetris_batch* b) { return b ? NGWORDS + b->P * NWORDS : 0; }
-int tetris_table_chunks(const tetris_batch* b) { return b ? (int)b->tab->chunks.size() : 0; }
+int tetris_table_chunks(const tetris_batch* b) { return b ? b->tab->n_chunks : 0; }
 void* tetris_device_state(tetris_batch* b) { return b ? b->state.data() : nullptr; }
 void* tetris_stream(tetris_batch*) { return nullptr; }
 int tetris_is_cpu_harness(void) { return 1; }
@@ -268,8 +267,8 @@ int tetris_set_dead(tetris_batch* b, const int32_t* idx, int n, const uint8_t* d
 
 int tetris_rollout_random(tetris_batch* b, int launches, int steps_per_launch, uint32_t policy_seed, uint64_t first_step, int ms,
                           uint64_t counters[4], float* elapsed_ms) {
-    if (launches < 1 || steps_per_launch < 1 || steps_per_launch > 256) return fail(TETRIS_E_ARG, "launches/steps_per_launch");
-    const int group = 256 / steps_per_launch;
+    if (launches < 1 || steps_per_launch < 0 || steps_per_launch > 256) return fail(TETRIS_E_ARG, "launches/steps_per_launch");
+    const int group = steps_per_launch ? 256 / steps_per_launch : 256;   // 0 = load/store only (diagnostic floor)
     const uint32_t saved = b->margin;
     b->margin = (uint32_t)(2 * group * steps_per_launch + 16);
     if (b->margin < saved) b->margin = saved;
