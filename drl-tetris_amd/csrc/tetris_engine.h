@@ -127,6 +127,7 @@ struct Game {
     uint32_t seed16;                 // low 16 bits of the seed (table row)
     int round_over, last_winner;
     uint32_t episode;
+    uint32_t roll_lines, roll_sent;  // cumulative rollout counters (G_LINES, G_SENT)
     uint32_t status;                 // te::Status bits raised while stepping this game
 };
 
@@ -139,6 +140,8 @@ TE_HD void load_game(const uint32_t* state, const uint32_t* gstate, size_t n, si
     g.round_over = (meta >> 16) & 1;
     g.last_winner = (int)((meta >> 17) & 0xF) - 1;
     g.episode = ld_stream(&gstate[(size_t)G_EPISODE * n + slot]);
+    g.roll_lines = ld_stream(&gstate[(size_t)G_LINES * n + slot]);
+    g.roll_sent = ld_stream(&gstate[(size_t)G_SENT * n + slot]);
     g.status = 0;
     TE_UNROLL
     for (int p = 0; p < P; p++) {
@@ -185,6 +188,8 @@ template <int P>
 TE_HD void store_game(uint32_t* state, uint32_t* gstate, size_t n, size_t slot, const Game<P>& g) {
     st_stream(&gstate[(size_t)G_META * n + slot], g.seed16 | ((uint32_t)g.round_over << 16) | ((uint32_t)(g.last_winner + 1) << 17));
     st_stream(&gstate[(size_t)G_EPISODE * n + slot], g.episode);
+    st_stream(&gstate[(size_t)G_LINES * n + slot], g.roll_lines);
+    st_stream(&gstate[(size_t)G_SENT * n + slot], g.roll_sent);
     TE_UNROLL
     for (int p = 0; p < P; p++) {
         const Player& q = g.pl[p];
@@ -591,7 +596,7 @@ TE_HD void init_game(const Ctx& cx, Game<P>& g, uint32_t seed16) {
         q.reward = 0; q.inc_count = 0; q.combo_remaining = 0; q.dead = 0; q.next = 0; q.kind = 7; q.rot = 0;
         q.q_loaded = 1;
     }
-    g.episode = 0; g.status = 0;
+    g.episode = 0; g.roll_lines = 0; g.roll_sent = 0; g.status = 0;
     reset_game(cx, g, seed16);
     g.last_winner = -1;
 }

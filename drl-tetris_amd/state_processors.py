@@ -22,7 +22,7 @@ def state_dict(x, player, *parameters):
         "incoming_lines": np.array(s.inc_lines),
         "combo_time": np.array(min(25000, s.combo_time + 50) // 100, dtype=np.uint8),
         "combo_count": np.array(s.combo_count, dtype=np.uint8),
-        "nextpiece": np.array([int(p == s.nextpiece) for p in piece_set], dtype=np.uint8),
+        "nextpiece": np.array([int(p == s.nextpiece[0]) for p in piece_set], dtype=np.uint8),
     }
     if separate_piece:
         ret["piece_idx"] = current
@@ -31,7 +31,7 @@ def state_dict(x, player, *parameters):
         ret["aug"] = {
             "field": ret["field"][:, ::-1],
             "piece": np.array([int(p == mirrored) for p in piece_set]).astype(np.uint8),
-            "nextpiece": np.array([MIRROR_PIECE[int(p == s.nextpiece)] for p in piece_set], dtype=np.uint8),   # sic: state_processors.py:50
+            "nextpiece": np.array([MIRROR_PIECE[int(p == s.nextpiece[0])] for p in piece_set], dtype=np.uint8),   # sic: state_processors.py:50
             "piece_idx": mirrored,
         }
     return ret
