@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""profiles/pmc_p{P}_s{S}.json (read by bench.py for roofline.traffic) from a pmc_passes.sh summary.
+HBM-side bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) KiB: WRITE_SIZE is exact and FETCH_SIZE reads 1/2 on
+gfx950 for this kernel's access pattern — calibrated with profiles/calib.py (zero-step launches moving exactly
+30 words x 4 B x 65536 games each way: FETCH_SIZE 3879 KiB vs 7680 KiB known, WRITE/WRREQ exact), as
+MI355X_MICROARCH.md §HBM prescribes.  The x2 is calibrated for the coalesced state stream; for the scattered
+one-byte RNG-table reads it is an upper bound.  Infinity-Cache hits are included in these fabric-side counters."""
+import json, sys
+summary, P, S, out = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+d = json.load(open(summary))
+k = [v for name, v in d.items() if f"k_game<{P}, 6>" in name][0]
+res = {
+    "kernel": f"k_game<{P}, M_ROLLOUT>", "steps_per_launch": S, "games": 65536,
+    "FETCH_SIZE_KiB_raw": k["FETCH_SIZE"], "WRITE_SIZE_KiB": k["WRITE_SIZE"],
+    "fetch_correction": 2.0,
+    "hbm_bytes_per_launch": int((2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024),
+    "TCC_HIT_sum": k.get("TCC_HIT_sum"), "TCC_MISS_sum": k.get("TCC_MISS_sum"),
+    "TCC_EA0_RDREQ_sum": k.get("TCC_EA0_RDREQ_sum"), "TCC_EA0_WRREQ_sum": k.get("TCC_EA0_WRREQ_sum"),
+    "source": summary,
+}
+for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_WAVES", "SQ_WAVE_CYCLES",
+          "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "GRBM_GUI_ACTIVE"):
+    if c in k:
+        res[c] = k[c]
+json.dump(res, open(out, "w"), indent=1)
+print(out, res["hbm_bytes_per_launch"])
