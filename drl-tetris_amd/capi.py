@@ -62,6 +62,7 @@ _SIGNATURES = {
     "tetris_snapshot": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "tetris_restore": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "tetris_set_dead": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "tetris_enumerate_drops": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "tetris_rollout_random": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_uint32, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p]),
     "tetris_device_state": (C.c_void_p, [C.c_void_p]),
     "tetris_stream": (C.c_void_p, [C.c_void_p]),
@@ -205,6 +206,17 @@ class TetrisBatch:
     def set_dead(self, dead, idx=None):
         a, n = self._idx(idx)
         self._check(self.lib.tetris_set_dead(self._h, _p(a), n, _p(_u8(dead, (n, self.n_players)))))
+
+    def enumerate_drops(self, idx=None, player=None, columns=True):
+        """-> valid u8 [n,4,10], land_y i8 [n,4,10], cleared u8 [n,4,10], after u32 [n,4,10,10] column bitboards (or None)"""
+        a, n = self._idx(idx)
+        pl = None if player is None else _u8(np.broadcast_to(player, (n,)))
+        valid = np.zeros((n, 4, 10), np.uint8)
+        land = np.zeros((n, 4, 10), np.int8)
+        cleared = np.zeros((n, 4, 10), np.uint8)
+        after = np.zeros((n, 4, 10, 10), np.uint32) if columns else None
+        self._check(self.lib.tetris_enumerate_drops(self._h, _p(a), n, _p(pl), _p(valid), _p(land), _p(cleared), _p(after)))
+        return valid, land, cleared, after
 
     def rollout_random(self, launches, steps_per_launch=1, policy_seed=0xD71, first_step=0, ms=400):
         """-> (counters[4] = env_steps, episodes, lines, sent; elapsed_ms on the batch's stream)"""

@@ -79,6 +79,14 @@ __global__ __launch_bounds__(256) void k_observe(const uint32_t* state, const ui
     if (i < n) observe_body<P>(state, gstate, n_games, i, idx, H, d_shape_table.s, rec, round_over, last_winner);
 }
 
+template <int P>
+__global__ __launch_bounds__(256) void k_enumerate(const uint32_t* state, int n_games, int n, const int32_t* idx,
+                                                   const uint8_t* player, int H, uint8_t* valid, int8_t* land_y,
+                                                   uint8_t* cleared, uint32_t* after) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < (size_t)n * 40) enumerate_body<P>(state, n_games, t, idx, player, H, d_shape_table.s, valid, land_y, cleared, after);
+}
+
 __global__ __launch_bounds__(256) void k_snapshot(uint32_t* state, uint32_t* gstate, int n_games, int n, const int32_t* idx,
                                                   int P, uint32_t* blob, int restore) {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -604,6 +612,45 @@ int tetris_set_dead(tetris_batch* b, const int32_t* idx, int n, const uint8_t* d
                        d_idx, b->P, (const uint8_t*)b->s_in0.d);
     HIP_TRY(hipGetLastError());
     return finish_call(b);
+}
+
+int tetris_enumerate_drops(tetris_batch* b, const int32_t* idx, int n, const uint8_t* player, uint8_t* valid, int8_t* land_y,
+                           uint8_t* cleared, uint32_t* after) {
+    int rc = check_batch(b);
+    if (rc) return rc;
+    if (!valid || !land_y || !cleared) return fail(TETRIS_E_ARG, "valid/land_y/cleared are NULL");
+    const int32_t* d_idx;
+    if ((rc = stage_idx(b, idx, n, &d_idx))) return rc;
+    if (n == 0) return TETRIS_OK;
+    const uint8_t* d_player = nullptr;
+    if (player) {
+        for (int i = 0; i < n; i++)
+            if (player[i] >= b->P) return fail(TETRIS_E_ARG, "player index out of range");
+        if ((rc = stage_in(b, b->s_in0, player, (size_t)n))) return rc;
+        d_player = (const uint8_t*)b->s_in0.d;
+    }
+    const size_t lanes = (size_t)n * 40;
+    if ((rc = b->s_out0.ensure(lanes + 4))) return rc;
+    if ((rc = b->s_out1.ensure(lanes + 4))) return rc;
+    if ((rc = b->s_out2.ensure(lanes + 4))) return rc;
+    if (after && (rc = b->s_big.ensure(lanes * NCOL * 4 + 16))) return rc;
+    uint32_t* d_after = after ? (uint32_t*)b->s_big.d : nullptr;
+    dim3 grid((unsigned)((lanes + 255) / 256)), block(256);
+    if (b->P == 1)
+        hipLaunchKernelGGL(k_enumerate<1>, grid, block, 0, b->stream, b->d_state, b->N, n, d_idx, d_player, b->H,
+                           (uint8_t*)b->s_out0.d, (int8_t*)b->s_out1.d, (uint8_t*)b->s_out2.d, d_after);
+    else
+        hipLaunchKernelGGL(k_enumerate<2>, grid, block, 0, b->stream, b->d_state, b->N, n, d_idx, d_player, b->H,
+                           (uint8_t*)b->s_out0.d, (int8_t*)b->s_out1.d, (uint8_t*)b->s_out2.d, d_after);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(b->s_out0.h, b->s_out0.d, lanes, hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipMemcpyAsync(b->s_out1.h, b->s_out1.d, lanes, hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipMemcpyAsync(b->s_out2.h, b->s_out2.d, lanes, hipMemcpyDeviceToHost, b->stream));
+    if (after) HIP_TRY(hipMemcpyAsync(b->s_big.h, b->s_big.d, lanes * NCOL * 4, hipMemcpyDeviceToHost, b->stream));
+    if ((rc = finish_call(b))) return rc;
+    memcpy(valid, b->s_out0.h, lanes); memcpy(land_y, b->s_out1.h, lanes); memcpy(cleared, b->s_out2.h, lanes);
+    if (after) memcpy(after, b->s_big.h, lanes * NCOL * 4);
+    return TETRIS_OK;
 }
 
 int tetris_rollout_random(tetris_batch* b, int launches, int steps_per_launch, uint32_t policy_seed, uint64_t first_step,

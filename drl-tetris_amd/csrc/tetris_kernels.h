@@ -235,6 +235,40 @@ TE_HD void observe_body(const uint32_t* state, const uint32_t* gstate, int n_gam
     }
 }
 
+// TestField.cpp:64-125 (drop placements): lane t = (game i, rotation r, column index xi)
+template <int P>
+TE_HD void enumerate_body(const uint32_t* state, int n_games, size_t t, const int32_t* idx, const uint8_t* player, int H,
+                          const uint32_t* shapes, uint8_t* valid, int8_t* land_y, uint8_t* cleared, uint32_t* after) {
+    const int i = (int)(t / 40), j = (int)(t % 40), r = j / 10, xi = j % 10;
+    const size_t slot = idx ? (size_t)idx[i] : (size_t)i;
+    const int p = player ? player[i] : 0;
+    const size_t ws = (size_t)P * n_games;
+    const uint32_t* s = state + (size_t)p * n_games + slot;
+    Player q;
+    for (int c = 0; c < NCOL; c++) q.col[c] = s[(size_t)(W_COL0 + c) * ws];
+    const uint32_t w = s[(size_t)W_PIECE * ws];
+    const int kind = w & 7, cur_rot = (w >> 3) & 3;
+    Ctx cx;
+    cx.shapes = shapes; cx.H = H; cx.floor_bits = ~0u << H;
+    const int n_rot = kind == 6 ? 1 : (kind == 4 || kind == 2 || kind == 3) ? 2 : 4;     // TestField.cpp:71-109
+    const int rot = kind == 6 ? cur_rot : r;                                               // O is used as it stands
+    const uint32_t shape = shapes[((kind & 7) << 2) | rot];
+    q.kind = kind; q.rot = rot; q.x = xi - 1; q.y = 0;
+    bool ok = kind <= 6 && r < n_rot && q.x <= NCOL - 2 && fits_at(cx, q, shape, q.x, 0);
+    int y = 0, gone = 0;
+    if (ok) {
+        y = drop_distance(cx, q, shape);
+        q.y = y;
+        stamp(q, shape);
+    }
+    valid[t] = ok ? 1 : 0;
+    land_y[t] = (int8_t)y;
+    if (after)
+        for (int c = 0; c < NCOL; c++) after[t * NCOL + c] = q.col[c];
+    if (ok) gone = clear_rows(cx, q);
+    cleared[t] = (uint8_t)gone;
+}
+
 // per-game cumulative rollout counters of one game -> {episodes, lines, sent}
 TE_HD void totals_of_game(const uint32_t* gstate, int n_games, int i, unsigned long long out[3]) {
     out[0] = gstate[(size_t)G_EPISODE * n_games + i];

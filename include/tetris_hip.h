@@ -115,6 +115,16 @@ int tetris_restore(tetris_batch *b, const int32_t *idx, int n, const uint32_t *b
 /* replaces: Python writing State.dead on a live handle (data_types/state.py:11,16). dead[n][P]  */
 int tetris_set_dead(tetris_batch *b, const int32_t *idx, int n, const uint8_t *dead);
 
+/* replaces: the drop part of PythonHandle.get_actions(player) + simulate_actions(finalize=False)
+ * (TestField.cpp:64-125 getMask/findNextMove; tetris_environment.py:87-100): for every listed game, the current
+ * piece of player[i] (NULL = player 0) placed at (x, 0), x = xi - 1 for xi = 0..9, with absolute rotation r = 0..3
+ * (only the rotations the reference enumerates: 1 for O, 2 for I/S/Z, 4 for L/J/T); where it fits it is hard-dropped
+ * and stamped.  valid/land_y/cleared [n][4][10] (cleared = rows a finalize would remove);
+ * after [n][4][10][10] = the stamped board's column bitboards before line clear (NULL to skip).  One lane per
+ * (game, r, x): 40 lanes per board.                                                                              */
+int tetris_enumerate_drops(tetris_batch *b, const int32_t *idx, int n, const uint8_t *player, uint8_t *valid,
+                           int8_t *land_y, uint8_t *cleared, uint32_t *after);
+
 /* Built-in synthetic rollout = the worker loop of drl_tetris/worker.py:91-118 with a random policy
  * (SURVEY.md §8d): per env-step  Philox4x32-10(policy_seed; game, step) -> (r = w0 & 3,
  * t = w1 mod 10), acting player = step mod P, perform_action, auto-reset of finished games with

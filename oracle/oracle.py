@@ -95,6 +95,7 @@ def lib():
     L.or_observe.argtypes = [vp, vp, i32, vp, vp, vp]
     L.or_copy_games.argtypes = [vp, vp, vp, vp, i32]
     L.or_set_dead.argtypes = [vp, vp, i32, vp]
+    L.or_enumerate_drops.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp]
     L.or_rollout_random.argtypes = [vp, C.c_uint32, C.c_uint64, i32, i32, vp, vp, i32]
     L.or_mt19937_block.argtypes = [C.c_uint32, vp, i32]
     L.or_philox4x32_10.argtypes = [C.c_uint32] * 6 + [vp]
@@ -181,6 +182,17 @@ class OracleBatch:
         a, n = _idx(idx, self.n_games)
         dead = np.ascontiguousarray(dead, dtype=np.uint8).reshape(n, self.n_players)
         self.L.or_set_dead(self.h, _p(a), n, _p(dead))
+
+    def enumerate_drops(self, idx=None, player=None, cells=True):
+        """-> valid u8 [n,4,10], land_y i8 [n,4,10], cleared u8 [n,4,10], after u8 [n,4,10,H,W] (or None)"""
+        a, n = _idx(idx, self.n_games)
+        pl = None if player is None else np.ascontiguousarray(np.broadcast_to(player, (n,)), dtype=np.uint8)
+        valid = np.zeros((n, 4, 10), np.uint8)
+        land = np.zeros((n, 4, 10), np.int8)
+        cleared = np.zeros((n, 4, 10), np.uint8)
+        after = np.zeros((n, 4, 10, self.height, self.width), np.uint8) if cells else None
+        self.L.or_enumerate_drops(self.h, _p(a), n, _p(pl), _p(valid), _p(land), _p(cleared), _p(after))
+        return valid, land, cleared, after
 
     def get_actions(self, game, player, max_lists=256, max_keys=64):
         keys = np.zeros((max_lists, max_keys), np.uint8)

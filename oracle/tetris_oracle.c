@@ -710,6 +710,37 @@ void or_set_dead(or_batch *b, const int32_t *idx, int n, const uint8_t *dead) {
         for (int q = 0; q < b->n_players; q++) PL(b, idx ? idx[i] : i, q)->dead = dead[(size_t)i * b->n_players + q];
 }
 
+/* TestField.cpp:64-125 getMask / findNextMove, drop placements only */
+void or_enumerate_drops(const or_batch *b, const int32_t *idx, int n, const uint8_t *player, uint8_t *valid,
+                        int8_t *land_y, uint8_t *cleared, uint8_t *after_cells) {
+    const int cells = b->H * b->W;
+    for (int i = 0; i < n; i++) {
+        int g = idx ? idx[i] : i;
+        const player_t *src = PL(b, g, player ? player[i] : 0);
+        int kind = src->kind;
+        int n_rot = kind == 6 ? 1 : (kind == 4 || kind == 2 || kind == 3) ? 2 : 4;   /* TestField.cpp:71-109 */
+        for (int r = 0; r < 4; r++)
+            for (int xi = 0; xi < 10; xi++) {
+                size_t o = ((size_t)i * 4 + r) * 10 + xi;
+                valid[o] = 0; land_y[o] = 0; cleared[o] = 0;
+                if (after_cells) memcpy(after_cells + o * cells, src->cell, (size_t)cells);
+                int x = xi - 1;
+                int rot = kind == 6 ? src->rot : r;      /* O is used as it stands (TestField.cpp:71-80) */
+                if (kind > 6 || r >= n_rot || x > b->W - 2) continue;
+                if (!fits(b, src, kind, rot, x, 0)) continue;
+                player_t tmp = *src;
+                tmp.rot = (uint8_t)rot; tmp.px = (int8_t)x; tmp.py = 0;
+                drop_to_floor(b, &tmp);
+                stamp_piece(b, &tmp);
+                valid[o] = 1; land_y[o] = tmp.py;
+                if (after_cells) memcpy(after_cells + o * cells, tmp.cell, (size_t)cells);
+                int out[2];
+                clear_rows(b, &tmp, out);
+                cleared[o] = (uint8_t)out[0];
+            }
+    }
+}
+
 /* SURVEY.md §8(d) synthetic workload                                          */
 static int16_t episode_seed(int g, uint32_t e) {
     return (int16_t)(uint16_t)((12345u + 7919u * (uint32_t)g + 104729u * e) & 0xFFFFu);

@@ -123,6 +123,14 @@ void        or_set_dead(or_batch *b, const int32_t *idx, int n, const uint8_t *d
 int         or_get_actions(or_batch *b, int game, int player, uint8_t *keys, uint8_t *lens,
                            int max_lists, int max_keys);
 
+/* Drop part of TestField::getMask (TestField.cpp:64-125): for absolute rotation r = 0..3 and x = -1..W-2
+ * (index xi = x+1), in the reference's enumeration order x-major, r-minor: the current piece of `player`
+ * placed at (x, 0) with raw rotation r — if it fits there it is hard-dropped (gameField.cpp:49-53) and stamped.
+ * Rotations the reference does not enumerate (r >= 1 for O, r >= 2 for I/S/Z) are invalid.
+ * valid/land_y/cleared [n][4][10]; after_cells [n][4][10][H*W] (stamped, before line clear; NULL to skip).   */
+void        or_enumerate_drops(const or_batch *b, const int32_t *idx, int n, const uint8_t *player,
+                               uint8_t *valid, int8_t *land_y, uint8_t *cleared, uint8_t *after_cells);
+
 /* Seeded synthetic rollout used by bench.py's cpu_baseline leg and by the
  * parity tests: SURVEY.md §8(d) policy (Philox4x32-10 keyed (policy_seed, game,
  * step)), auto-reset with seed16 = (12345 + 7919 g + 104729 e) mod 65536.

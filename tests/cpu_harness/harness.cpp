@@ -265,6 +265,16 @@ int tetris_set_dead(tetris_batch* b, const int32_t* idx, int n, const uint8_t* d
     return TETRIS_OK;
 }
 
+int tetris_enumerate_drops(tetris_batch* b, const int32_t* idx, int n, const uint8_t* player, uint8_t* valid, int8_t* land_y,
+                           uint8_t* cleared, uint32_t* after) {
+    int rc = check_idx(b, idx, n); if (rc) return rc;
+    for (size_t t = 0; t < (size_t)n * 40; t++) {
+        if (b->P == 1) enumerate_body<1>(b->state.data(), b->N, t, idx, player, b->H, SHAPES.s, valid, land_y, cleared, after);
+        else enumerate_body<2>(b->state.data(), b->N, t, idx, player, b->H, SHAPES.s, valid, land_y, cleared, after);
+    }
+    return TETRIS_OK;
+}
+
 int tetris_rollout_random(tetris_batch* b, int launches, int steps_per_launch, uint32_t policy_seed, uint64_t first_step, int ms,
                           uint64_t counters[4], float* elapsed_ms) {
     if (launches < 1 || steps_per_launch < 0 || steps_per_launch > 256) return fail(TETRIS_E_ARG, "launches/steps_per_launch");

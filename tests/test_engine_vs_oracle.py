@@ -173,3 +173,29 @@ def test_rollout_random_matches_oracle(kind, P):
     assert int(c1[0]) == n * 192 and int(c1[1]) > 0
     engines.assert_same_state(eng, ref, where="fused rollout")
     engines.assert_same_state(eng2, ref, where="unfused rollout")
+
+
+@pytest.mark.parametrize("kind", engines.ENGINE_PARAMS)
+def test_enumerate_drops_matches_oracle(kind):
+    """BASELINE config 4 (SIXten-style enumeration): all rotation x column drop afterstates of the current piece
+    (TestField.cpp:64-125), on boards taken from mid-game, both players, against the oracle's cell-based version."""
+    n, P = (4096 if kind == "hip" else 256), 2
+    eng, ref = _pair(kind, n, P, seed_base=500)
+    rng = np.random.default_rng(9)
+    for s in range(24):
+        rot, trans = rng.integers(0, 4, n).astype(np.uint8), rng.integers(0, 10, n).astype(np.uint8)
+        eng.step_rt(rot, trans, s % 2)
+        ref.step_rt(rot, trans, s % 2)
+        if s in (11, 12, 23):
+            player = rng.integers(0, 2, n).astype(np.uint8)
+            v1, y1, c1, a1 = eng.enumerate_drops(player=player)
+            v2, y2, c2, a2 = ref.enumerate_drops(player=player)
+            assert np.array_equal(v1, v2) and np.array_equal(y1, y2) and np.array_equal(c1, c2)
+            # columns -> cells: bit y of column c = cell (y, c)
+            cells = ((a1[..., None, :] >> np.arange(20, dtype=np.uint32)[:, None]) & 1).astype(bool)      # [n,4,10,20,10]
+            assert np.array_equal(cells, a2 > 0)
+            assert v1.any(axis=(1, 2)).mean() > 0.9 and c1.max() <= 4
+    sub = np.arange(0, n, 3, dtype=np.int32)
+    v1, y1, c1, _ = eng.enumerate_drops(idx=sub, player=1, columns=False)
+    v2, y2, c2, _ = ref.enumerate_drops(idx=sub, player=1, cells=False)
+    assert np.array_equal(v1, v2) and np.array_equal(y1, y2) and np.array_equal(c1, c2)
