@@ -741,6 +741,236 @@ void or_enumerate_drops(const or_batch *b, const int32_t *idx, int n, const uint
     }
 }
 
+/* ------------------------------------------------------------------ get_actions (TestField.cpp)
+ * "place_block" enumeration: for every (x, rotation) that fits at the top row, the plain drop, then the
+ * placements deeper in the same column range that can be reached by sliding under an overhang or by a
+ * rotation with wall kick ("finesse"), each with the key list that produces it.  The search runs
+ * BACKWARDS from the landing position up to row 0 and records its path, which is replayed reversed.  */
+typedef struct {
+    const or_batch *b;
+    player_t pl;                 /* board copy + the probe piece */
+    int spawn_rot;
+    uint8_t path[512]; int path_len;          /* TestField::test_path                    */
+    uint8_t best_path[512]; int best_len;     /* MoveInfo::path                          */
+    int best_x, best_rot;                      /* MoveInfo::posX / rot                    */
+    uint8_t *keys, *lens; int max_lists, max_keys, n_lists;
+} probe_t;
+
+typedef struct { uint8_t rot; int8_t x, y; } pose_t;
+static pose_t pose_get(const probe_t *t) { pose_t p = {t->pl.rot, t->pl.px, t->pl.py}; return p; }
+static void pose_set(probe_t *t, pose_t p) { t->pl.rot = p.rot; t->pl.px = p.x; t->pl.py = p.y; }
+static int probe_fits(const probe_t *t) { return fits_now(t->b, &t->pl); }
+static void path_push(probe_t *t, int v) { if (t->path_len < 512) t->path[t->path_len++] = (uint8_t)v; }
+
+/* TestField.cpp:3-35 convert + emission of one key list */
+static int convert_code(int m) {
+    switch (m) { case 255: return 3; case 254: return 1; case 253: return 6; case 252: return 5;
+                 case 241: return 8; case 242: return 10; case 243: return 9; default: return m; }
+}
+static void emit_begin(probe_t *t, int *n) { *n = 0; (void)t; }
+static void emit_key(probe_t *t, int *n, int code) {
+    if (t->n_lists < t->max_lists && *n < t->max_keys) t->keys[(size_t)t->n_lists * t->max_keys + *n] = (uint8_t)convert_code(code);
+    (*n)++;
+}
+static void emit_end(probe_t *t, int n) {
+    if (t->n_lists < t->max_lists) t->lens[t->n_lists] = (uint8_t)(n < t->max_keys ? n : t->max_keys);
+    t->n_lists++;
+}
+/* TestField.cpp:37-42 addRotationValue, :44-49 makeStartSequence */
+static void emit_rotation(probe_t *t, int *n, int value) { if (value < 0) value += 4; if (value) emit_key(t, n, 240 + value); }
+static void emit_start_moves(probe_t *t, int *n, int x) {
+    int mid = (t->b->W - 4) / 2;
+    if (x > mid) for (int i = 0; i < x - mid; i++) emit_key(t, n, 255);
+    else for (int i = 0; i < mid - x; i++) emit_key(t, n, 254);
+}
+
+/* TestField.cpp:392-410 moveUp */
+static int probe_move_up(probe_t *t) {
+    int landed = 0;
+    t->pl.py++;
+    if (!probe_fits(t)) landed = 1;
+    t->pl.py--;
+    int count = 0;
+    do { t->pl.py--; count++; } while (probe_fits(t));
+    count--;
+    t->pl.py++;
+    if (count && landed) return 253;
+    return count & 255;
+}
+
+/* TestField.cpp:166-172 setFinesseMove */
+static int probe_commit(probe_t *t) {
+    memcpy(t->best_path, t->path, (size_t)t->path_len);
+    t->best_len = t->path_len; t->best_x = t->pl.px; t->best_rot = t->pl.rot;
+    return 1;
+}
+
+/* TestField.cpp:202-238 tryLeft / tryRight (tail recursion written as a loop) */
+static int probe_slide(probe_t *t, int dir, int clear_first) {
+    for (;;) {
+        if (!shift_piece(t->b, &t->pl, dir, 0)) return 0;
+        if (clear_first) t->path_len = 0;
+        clear_first = 0;
+        path_push(t, dir < 0 ? 255 : 254);
+        int up = probe_move_up(t);
+        if (up) path_push(t, up);
+        if (t->pl.py == 0) return probe_commit(t);
+    }
+}
+
+/* TestField.cpp:240-259 tryUp */
+static int probe_up(probe_t *t, int turn) {
+    t->path_len = 0;
+    int up = probe_move_up(t);
+    path_push(t, turn + 240);
+    if (up) path_push(t, up);
+    if (t->pl.py == 0) return probe_commit(t);
+    if (probe_slide(t, -1, 0)) return 1;
+    t->path_len = 0;
+    path_push(t, turn + 240);
+    if (up) path_push(t, up);
+    return probe_slide(t, +1, 0);
+}
+
+/* TestField.cpp:280-356 doWallKick: un-rotate (with the kick offsets mirrored in y) to a pose from which
+ * the forward rotation, kicks included, lands exactly on the target pose                              */
+static int probe_wallkick(probe_t *t) {
+    static const int8_t RDX[7] = {0, -1, +1, -1, +1, -2, +2};
+    static const int8_t RDY[7] = {-1, 0, 0, -1, -1, 0, 0};
+    const pose_t target = pose_get(t);
+    int r, found = 0;
+    for (r = 0; r < 4; r++) {
+        if (r == target.rot) continue;
+        t->pl.rot = (uint8_t)r;                 /* raw rotation keeps the position */
+        if (probe_fits(t)) {
+            int turn = (target.rot - r) & 3;
+            int ok = probe_up(t, turn);
+            pose_set(t, target);
+            return ok;
+        }
+        int base_x = t->pl.px, base_y = t->pl.py, k;
+        for (k = 0; k < 7; k++) {
+            t->pl.px = (int8_t)(base_x + RDX[k]); t->pl.py = (int8_t)(base_y + RDY[k]);
+            if (probe_fits(t)) break;
+        }
+        if (k < 7) { found = 1; break; }
+        t->pl.px = (int8_t)base_x; t->pl.py = (int8_t)base_y;
+    }
+    if (!found) { pose_set(t, target); return 0; }
+    int turn = (target.rot - r) & 3;
+    const pose_t from = pose_get(t);
+    if (turn == 0) { pose_set(t, target); return 0; }
+    rotate_piece(t->b, &t->pl, turn == 1 ? 1 : turn == 2 ? 2 : 3);     /* gameField.cpp:55-91, with kicks */
+    if (t->pl.px != target.x || t->pl.py != target.y) { pose_set(t, target); return 0; }
+    pose_set(t, from);
+    if (probe_up(t, turn)) { pose_set(t, target); return 1; }
+    pose_set(t, from);
+    t->path_len = 0;
+    path_push(t, 240 + turn);
+    if (probe_slide(t, -1, 0)) { pose_set(t, target); return 1; }
+    pose_set(t, from);
+    if (t->path_len > 1) { t->path_len = 0; path_push(t, 240 + turn); }
+    int ok = probe_slide(t, +1, 0);
+    pose_set(t, target);
+    return ok;
+}
+
+/* TestField.cpp:358-390 r180KeepPos */
+static void probe_flip_keep_pos(probe_t *t) {
+    t->pl.rot = (uint8_t)((t->pl.rot + 2) & 3);
+    int k = t->pl.kind, r = t->pl.rot;
+    if (k == 4 || k == 3) { if (r == 0) t->pl.px++; else if (r == 1) t->pl.py++; else if (r == 2) t->pl.px--; else t->pl.py--; }
+    if (k == 2) { if (r == 0) t->pl.px--; else if (r == 1) t->pl.py--; else if (r == 2) t->pl.px++; else t->pl.py++; }
+}
+
+/* TestField.cpp:261-278 reverseWallkick */
+static int probe_reverse_kick(probe_t *t) {
+    if (t->pl.kind == 6) return 0;
+    if (shift_piece(t->b, &t->pl, +1, 0)) { shift_piece(t->b, &t->pl, -1, 0); return 0; }
+    if (shift_piece(t->b, &t->pl, -1, 0)) { shift_piece(t->b, &t->pl, +1, 0); return 0; }
+    const pose_t here = pose_get(t);
+    if (probe_wallkick(t)) { pose_set(t, here); return 1; }
+    if (t->pl.kind == 2 || t->pl.kind == 3 || t->pl.kind == 4) {
+        probe_flip_keep_pos(t);
+        int ok = probe_wallkick(t);
+        pose_set(t, here);
+        return ok;
+    }
+    pose_set(t, here);
+    return 0;
+}
+
+/* TestField.cpp:189-200 finesseIsPossible */
+static int probe_reachable(probe_t *t) {
+    const pose_t here = pose_get(t);
+    if (probe_reverse_kick(t)) { pose_set(t, here); return 1; }
+    pose_set(t, here);
+    if (probe_slide(t, -1, 1)) { pose_set(t, here); return 1; }
+    int ok = probe_slide(t, +1, 1);
+    pose_set(t, here);
+    return ok;
+}
+
+/* TestField.cpp:127-164 useFinesseMove (use_mask == 2 branch) */
+static void probe_emit_finesse(probe_t *t) {
+    int n;
+    emit_begin(t, &n);
+    emit_rotation(t, &n, t->best_rot - t->spawn_rot);
+    emit_start_moves(t, &n, t->best_x);
+    for (int i = t->best_len - 1; i >= 0; i--) {
+        int v = t->best_path[i];
+        if (v < 240) for (int k = 0; k < v; k++) emit_key(t, &n, 252);
+        else emit_key(t, &n, v);
+    }
+    emit_key(t, &n, 7);
+    emit_end(t, n);
+}
+
+/* TestField.cpp:113-125 findNextMove + :174-187 tryAllFinesseMoves */
+static void probe_column(probe_t *t) {
+    int n;
+    emit_begin(t, &n);
+    emit_rotation(t, &n, (int)t->pl.rot - t->spawn_rot);
+    emit_start_moves(t, &n, t->pl.px);
+    emit_key(t, &n, 7);
+    emit_end(t, n);
+    drop_to_floor(t->b, &t->pl);
+    const pose_t landed = pose_get(t);
+    for (int y = landed.y + 2; y < t->b->H - 1; y++) {
+        pose_set(t, landed);
+        t->pl.py = (int8_t)y;
+        if (probe_fits(t)) {
+            drop_to_floor(t->b, &t->pl);
+            y = t->pl.py;
+            if (probe_reachable(t)) probe_emit_finesse(t);
+        }
+    }
+    pose_set(t, landed);
+}
+
+/* PythonHandle.cpp:190 get_actions -> gamePlay.cpp:232-239 getMask(2) -> TestField.cpp:64-111 */
+int or_get_actions(or_batch *b, int game, int player, uint8_t *keys, uint8_t *lens, int max_lists, int max_keys) {
+    probe_t *t = (probe_t *)calloc(1, sizeof *t);
+    t->b = b;
+    t->pl = *PL(b, game, player);
+    t->keys = keys; t->lens = lens; t->max_lists = max_lists; t->max_keys = max_keys;
+    int kind = t->pl.kind;
+    t->spawn_rot = kind <= 6 ? SPAWN_ROT[kind] : 0;
+    int start_rot = t->pl.rot;
+    int n_rot = kind == 6 ? 1 : (kind == 4 || kind == 2 || kind == 3) ? 2 : 4;
+    if (kind <= 6)
+        for (int x = -1; x < b->W - 1; x++)
+            for (int r = 0; r < n_rot; r++) {
+                t->pl.px = (int8_t)x; t->pl.py = 0;
+                t->pl.rot = (uint8_t)(kind == 6 ? start_rot : r);
+                if (!probe_fits(t)) continue;
+                probe_column(t);
+            }
+    int n = t->n_lists;
+    free(t);
+    return n;
+}
+
 /* SURVEY.md §8(d) synthetic workload                                          */
 static int16_t episode_seed(int g, uint32_t e) {
     return (int16_t)(uint16_t)((12345u + 7919u * (uint32_t)g + 104729u * e) & 0xFFFFu);

@@ -24,7 +24,7 @@ from tests.golden.ref_driver import RefGame  # noqa: E402
 MAXK = 32
 
 
-def record_trace(name, P, H, pieces, seed0, steps, policy, sloppiness=0.0, early_reset_every=0):
+def record_trace(name, P, H, pieces, seed0, steps, policy, sloppiness=0.0, early_reset_every=0, record_actions=False):
     """One game driven for `steps` env-steps; reset with seed0 + 17*episode on done."""
     rng = np.random.default_rng(abs(hash((name, seed0))) % (2**32))
     ref = RefGame(P, H, 10, pieces=pieces, seed=seed0)
@@ -33,6 +33,17 @@ def record_trace(name, P, H, pieces, seed0, steps, policy, sloppiness=0.0, early
 
     ev_kind, ev_seed, ev_player, ev_keys, ev_len, ev_done = [], [], [], [], [], []
     recs, ro, lw = [], [], []
+    act_keys, act_lens, act_n, act_player = [], [], [], []     # get_actions(player) BEFORE each event's action
+    MAXA, MAXAK = 64, 40
+
+    def snap_actions(player):
+        lists = ref.get_actions(player) if record_actions else []
+        k = np.zeros((MAXA, MAXAK), np.uint8); l = np.zeros(MAXA, np.uint8)
+        assert len(lists) <= MAXA and all(len(a) <= MAXAK for a in lists)
+        for i, a in enumerate(lists):
+            k[i, : len(a)] = a; l[i] = len(a)
+        act_keys.append(k); act_lens.append(l); act_n.append(len(lists)); act_player.append(player)
+        return lists
 
     def snap():
         r, o, w = ref.record()
@@ -40,6 +51,7 @@ def record_trace(name, P, H, pieces, seed0, steps, policy, sloppiness=0.0, early
 
     def do_reset(seed):
         ref.reset(seed); shadow.reset(seeds=seed)
+        snap_actions(0)
         ev_kind.append(0); ev_seed.append(seed); ev_player.append(0)
         ev_keys.append(np.zeros(MAXK, np.uint8)); ev_len.append(0); ev_done.append(0)
         snap()
@@ -47,12 +59,16 @@ def record_trace(name, P, H, pieces, seed0, steps, policy, sloppiness=0.0, early
     # event 0: state right after construction (PythonHandle ctor with time()==seed0)
     ev_kind.append(2); ev_seed.append(seed0); ev_player.append(0)
     ev_keys.append(np.zeros(MAXK, np.uint8)); ev_len.append(0); ev_done.append(0)
+    snap_actions(0)
     snap()
     do_reset(seed0)     # tetris_environment.__init__ always resets once (tetris_environment.py:40-41)
     episode = 0
     for s in range(steps):
         player = s % P
-        if policy == "rt":
+        lists = snap_actions(player)
+        if policy == "actions":
+            keys = lists[int(rng.integers(len(lists)))]
+        elif policy == "rt":
             keys = rt_keys(rng.integers(4), rng.integers(10))
         elif policy == "keys":
             keys = list(rng.integers(0, 11, size=rng.integers(0, 14)))
@@ -85,6 +101,9 @@ def record_trace(name, P, H, pieces, seed0, steps, policy, sloppiness=0.0, early
         ev_keys=np.stack(ev_keys), ev_len=np.array(ev_len, np.uint8), ev_done=np.array(ev_done, np.uint8),
         records=np.stack(recs), round_over=np.array(ro, np.uint8), last_winner=np.array(lw, np.int8),
     )
+    if record_actions:
+        out.update(act_keys=np.stack(act_keys), act_lens=np.stack(act_lens), act_n=np.array(act_n, np.int32),
+                   act_player=np.array(act_player, np.uint8))
     path = os.path.join(HERE, f"trace_{name}.npz")
     np.savez_compressed(path, **out)
     cleared = int(out["records"]["reward"][out["ev_kind"] == 1].sum())
@@ -152,6 +171,11 @@ def main():
     record_trace("greedy_2p_o", 2, 20, [6], 11, 1500, "greedy", sloppiness=0.02)
     record_trace("rt_2p_sz", 2, 20, [2, 3], 5, 800, "rt")
     record_trace("drop_2p", 2, 20, allp, 1000, 120, "drop")
+    # get_actions() lists (TestField.cpp:64-415) recorded before every step; the policy plays one of them, so
+    # tucks and spins create overhangs that later enumerations have to reach
+    record_trace("actions_2p", 2, 20, allp, 4, 500, "actions", record_actions=True)
+    record_trace("actions_1p_22", 1, 22, allp, 21, 400, "actions", record_actions=True)
+    record_trace("actions_2p_greedy", 2, 20, allp, 3, 300, "greedy", sloppiness=0.3, record_actions=True)
     np.savez_compressed(os.path.join(HERE, "rotation_table.npz"), table=rotation_table())
     np.savez_compressed(os.path.join(HERE, "rng_kat.npz"), **rng_kat())
     print("done")

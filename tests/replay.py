@@ -33,7 +33,7 @@ def compare(got, want, fields, occupancy_only=False, where=""):
             raise AssertionError(f"{where}: field '{f}' differs\n got  {a.tolist() if a.size < 64 else a}\n want {b.tolist() if b.size < 64 else b}")
 
 
-def replay(trace, make_engine, fields=None, occupancy_only=False, max_events=None):
+def replay(trace, make_engine, fields=None, occupancy_only=False, max_events=None, check_actions=False):
     """make_engine(n_players, height, width, pieces, seed) -> engine with one game."""
     P, H = int(trace["n_players"]), int(trace["height"])
     fields = fields or (VISIBLE + HIDDEN)
@@ -43,8 +43,16 @@ def replay(trace, make_engine, fields=None, occupancy_only=False, max_events=Non
     eng = None
     first_step_seen = False
     n = len(kinds) if max_events is None else min(len(kinds), max_events)
+    has_actions = check_actions and "act_n" in trace.files
+    if has_actions:      # NpzFile decompresses on every access: read once
+        act_keys, act_lens, act_n, act_player = trace["act_keys"], trace["act_lens"], trace["act_n"], trace["act_player"]
     for e in range(n):
         k = int(kinds[e])
+        if has_actions and k == 1:
+            # get_actions(player) of the state BEFORE this event's action (recorded from the reference)
+            want_lists = [act_keys[e][i, : act_lens[e][i]].tolist() for i in range(int(act_n[e]))]
+            got_lists = eng.get_actions(0, int(act_player[e]))
+            assert got_lists == want_lists, f"event {e}: get_actions differs ({len(got_lists)} vs {len(want_lists)} lists)"
         if k == 2:
             eng = make_engine(P, H, int(trace["width"]), trace["pieces"].tolist(), int(seeds[e]))
         elif k == 0:
