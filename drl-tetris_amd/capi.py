@@ -63,6 +63,7 @@ _SIGNATURES = {
     "tetris_restore": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "tetris_set_dead": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "tetris_enumerate_drops": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "tetris_get_actions": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "tetris_rollout_random": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_uint32, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p]),
     "tetris_device_state": (C.c_void_p, [C.c_void_p]),
     "tetris_stream": (C.c_void_p, [C.c_void_p]),
@@ -217,6 +218,19 @@ class TetrisBatch:
         after = np.zeros((n, 4, 10, 10), np.uint32) if columns else None
         self._check(self.lib.tetris_enumerate_drops(self._h, _p(a), n, _p(pl), _p(valid), _p(land), _p(cleared), _p(after)))
         return valid, land, cleared, after
+
+    def get_actions(self, idx=None, player=None, max_lists=64, max_keys=48):
+        """The reference's ordered key lists per game (PythonHandle.get_actions; masks[p].action).
+        `idx` may be an int (one game -> one list of lists) or None/array (-> list per game)."""
+        single = isinstance(idx, (int, np.integer))
+        a, n = self._idx([idx] if single else idx)
+        pl = None if player is None else _u8(np.broadcast_to(player, (n,)))
+        keys = np.zeros((n, max_lists, max_keys), np.uint8)
+        lens = np.zeros((n, max_lists), np.uint8)
+        count = np.zeros(n, np.int32)
+        self._check(self.lib.tetris_get_actions(self._h, _p(a), n, _p(pl), _p(keys), _p(lens), _p(count), max_lists, max_keys))
+        out = [[keys[i, k, : lens[i, k]].tolist() for k in range(count[i])] for i in range(n)]
+        return out[0] if single else out
 
     def rollout_random(self, launches, steps_per_launch=1, policy_seed=0xD71, first_step=0, ms=400):
         """-> (counters[4] = env_steps, episodes, lines, sent; elapsed_ms on the batch's stream)"""

@@ -718,6 +718,237 @@ TE_HD void play_rt(const Ctx& cx, Player& q, int r, int t) {
     q.lock_armed = 0;
 }
 
+// ---------------------------------------------------------------- get_actions (TestField.cpp:64-415)
+// "place_block" enumeration for ONE (x, rotation) start: the plain drop, then every deeper resting place in
+// that column range that can be reached by sliding under an overhang or by a rotation with wall kick, each
+// with the key list that produces it.  The search runs backwards from the landing pose up to row 0,
+// recording its path (255/254 = slid left/right, 24x = rotation, 253 = dropped to the floor, n < 240 = n rows),
+// which is replayed reversed (TestField.cpp:3-35,127-164).  Poses may stick out above row 0 (y < 0).
+constexpr int PROBE_PATH = 96;
+struct Probe {
+    Player q;                       // board + pose (kind, rot, x, y)
+    int spawn;
+    uint8_t path[PROBE_PATH]; int path_len;
+    uint8_t best[PROBE_PATH]; int best_len, best_x, best_rot;
+    uint8_t* keys; uint8_t* lens;   // this lane's slab: keys[max_lists][max_keys], lens[max_lists]
+    int max_lists, max_keys, n_lists, overflow;
+};
+struct Pose { int rot, x, y; };
+TE_HD Pose pose_get(const Probe& t) { Pose p = {t.q.rot, t.q.x, t.q.y}; return p; }
+TE_HD void pose_set(Probe& t, Pose p) { t.q.rot = p.rot; t.q.x = p.x; t.q.y = p.y; }
+
+// gameField.cpp:10-20 possible() for any y >= -3: cells above row 0 collide
+TE_HD bool fits_any(const Ctx& cx, const Player& q, uint32_t shape, int x, int y) {
+    if (y >= 0) return fits_at(cx, q, shape, x, y);
+    int k = -y;
+    if (k > 3) return (shape & 0xFFFFu) == 0;
+    uint32_t low = ((1u << k) - 1u) * 0x1111u;
+    if (shape & low) return false;
+    return fits_at(cx, q, ((shape & 0xFFFFu) >> k) & ((0xFu >> k) * 0x1111u), x, 0);
+}
+TE_HD bool probe_fits(const Ctx& cx, const Probe& t) { return fits_any(cx, t.q, shape_of(cx, t.q.kind, t.q.rot), t.q.x, t.q.y); }
+TE_HD bool probe_shift(const Ctx& cx, Probe& t, int dx) {
+    if (fits_any(cx, t.q, shape_of(cx, t.q.kind, t.q.rot), t.q.x + dx, t.q.y)) { t.q.x += dx; return true; }
+    return false;
+}
+TE_HD void probe_drop(const Ctx& cx, Probe& t) { t.q.y += drop_distance(cx, t.q, shape_of(cx, t.q.kind, t.q.rot)); }
+TE_HD void path_push(Probe& t, int v) { if (t.path_len < PROBE_PATH) t.path[t.path_len++] = (uint8_t)v; else t.overflow = 1; }
+
+TE_HD int convert_code(int m) {                                   // TestField.cpp:3-35
+    return m == 255 ? 3 : m == 254 ? 1 : m == 253 ? 6 : m == 252 ? 5 : m == 241 ? 8 : m == 242 ? 10 : m == 243 ? 9 : m;
+}
+TE_HD void emit_key(Probe& t, int& n, int code) {
+    if (t.n_lists < t.max_lists && n < t.max_keys) t.keys[t.n_lists * t.max_keys + n] = (uint8_t)convert_code(code);
+    else t.overflow = 1;
+    n++;
+}
+TE_HD void emit_end(Probe& t, int n) {
+    if (t.n_lists < t.max_lists) t.lens[t.n_lists] = (uint8_t)imin(n, t.max_keys);
+    t.n_lists++;
+}
+TE_HD void emit_rotation(Probe& t, int& n, int value) { value &= 3; if (value) emit_key(t, n, 240 + value); }   // :37-42
+TE_HD void emit_start_moves(Probe& t, int& n, int x) {                                                             // :44-49
+    const int mid = (NCOL - 4) / 2;
+    for (int i = 0; i < x - mid; i++) emit_key(t, n, 255);
+    for (int i = 0; i < mid - x; i++) emit_key(t, n, 254);
+}
+
+// TestField.cpp:392-410 moveUp
+TE_HD int probe_move_up(const Ctx& cx, Probe& t) {
+    t.q.y++;
+    const bool landed = !probe_fits(cx, t);
+    t.q.y--;
+    int count = 0;
+    do { t.q.y--; count++; } while (probe_fits(cx, t));
+    count--;
+    t.q.y++;
+    if (count && landed) return 253;
+    return count & 255;
+}
+
+TE_HD bool probe_commit(Probe& t) {                                 // TestField.cpp:166-172 setFinesseMove
+    for (int i = 0; i < t.path_len; i++) t.best[i] = t.path[i];
+    t.best_len = t.path_len; t.best_x = t.q.x; t.best_rot = t.q.rot;
+    return true;
+}
+
+// TestField.cpp:202-238 tryLeft / tryRight
+TE_HD bool probe_slide(const Ctx& cx, Probe& t, int dir, bool clear_first) {
+    for (;;) {
+        if (!probe_shift(cx, t, dir)) return false;
+        if (clear_first) t.path_len = 0;
+        clear_first = false;
+        path_push(t, dir < 0 ? 255 : 254);
+        int up = probe_move_up(cx, t);
+        if (up) path_push(t, up);
+        if (t.q.y == 0) return probe_commit(t);
+    }
+}
+
+// TestField.cpp:240-259 tryUp
+TE_HD bool probe_up(const Ctx& cx, Probe& t, int turn) {
+    t.path_len = 0;
+    int up = probe_move_up(cx, t);
+    path_push(t, turn + 240);
+    if (up) path_push(t, up);
+    if (t.q.y == 0) return probe_commit(t);
+    if (probe_slide(cx, t, -1, false)) return true;
+    t.path_len = 0;
+    path_push(t, turn + 240);
+    if (up) path_push(t, up);
+    return probe_slide(cx, t, +1, false);
+}
+
+// gameField.cpp:55-103 rcw/rccw/r180 with kicks, for poses that may stick out above row 0
+TE_HD void probe_rotate(const Ctx& cx, Probe& t, int turn) {
+    const int nr = (t.q.rot + turn) & 3;
+    const uint32_t shape = shape_of(cx, t.q.kind, nr);
+    const int x = t.q.x, y = t.q.y;
+    int dx = 99, dy = 0;
+    if (fits_any(cx, t.q, shape, x, y)) { dx = 0; }
+    else if (fits_any(cx, t.q, shape, x, y + 1)) { dx = 0; dy = 1; }
+    else if (fits_any(cx, t.q, shape, x - 1, y)) { dx = -1; }
+    else if (fits_any(cx, t.q, shape, x + 1, y)) { dx = 1; }
+    else if (fits_any(cx, t.q, shape, x - 1, y + 1)) { dx = -1; dy = 1; }
+    else if (fits_any(cx, t.q, shape, x + 1, y + 1)) { dx = 1; dy = 1; }
+    else if (fits_any(cx, t.q, shape, x - 2, y)) { dx = -2; }
+    else if (fits_any(cx, t.q, shape, x + 2, y)) { dx = 2; }
+    if (dx == 99) return;
+    t.q.rot = nr; t.q.x = x + dx; t.q.y = y + dy;
+}
+
+// TestField.cpp:280-356 doWallKick: un-rotate (kick offsets mirrored in y) to a pose from which the forward
+// rotation, kicks included, lands exactly on the target pose
+TE_HD bool probe_wallkick(const Ctx& cx, Probe& t) {
+    const Pose target = pose_get(t);
+    int r = 0;
+    bool found = false;
+    for (r = 0; r < 4 && !found; r++) {
+        if (r == target.rot) continue;
+        t.q.rot = r;
+        if (probe_fits(cx, t)) {
+            bool ok = probe_up(cx, t, (target.rot - r) & 3);
+            pose_set(t, target);
+            return ok;
+        }
+        const int bx = t.q.x, by = t.q.y;
+        for (int k = 0; k < 7 && !found; k++) {
+            // (0,-1) (-1,0) (+1,0) (-1,-1) (+1,-1) (-2,0) (+2,0)
+            const int ddx = (k == 0) ? 0 : (k == 1 || k == 3) ? -1 : (k == 2 || k == 4) ? 1 : (k == 5) ? -2 : 2;
+            const int ddy = (k == 0 || k == 3 || k == 4) ? -1 : 0;
+            t.q.x = bx + ddx; t.q.y = by + ddy;
+            if (probe_fits(cx, t)) found = true;
+        }
+        if (found) break;
+        t.q.x = bx; t.q.y = by;
+    }
+    if (!found) { pose_set(t, target); return false; }
+    const int turn = (target.rot - r) & 3;
+    const Pose from = pose_get(t);
+    if (turn == 0) { pose_set(t, target); return false; }
+    probe_rotate(cx, t, turn);
+    if (t.q.x != target.x || t.q.y != target.y) { pose_set(t, target); return false; }
+    pose_set(t, from);
+    if (probe_up(cx, t, turn)) { pose_set(t, target); return true; }
+    pose_set(t, from);
+    t.path_len = 0;
+    path_push(t, 240 + turn);
+    if (probe_slide(cx, t, -1, false)) { pose_set(t, target); return true; }
+    pose_set(t, from);
+    if (t.path_len > 1) { t.path_len = 0; path_push(t, 240 + turn); }
+    bool ok = probe_slide(cx, t, +1, false);
+    pose_set(t, target);
+    return ok;
+}
+
+// TestField.cpp:358-390 r180KeepPos
+TE_HD void probe_flip_keep_pos(Probe& t) {
+    t.q.rot = (t.q.rot + 2) & 3;
+    const int k = t.q.kind, r = t.q.rot;
+    if (k == 4 || k == 3) { if (r == 0) t.q.x++; else if (r == 1) t.q.y++; else if (r == 2) t.q.x--; else t.q.y--; }
+    if (k == 2) { if (r == 0) t.q.x--; else if (r == 1) t.q.y--; else if (r == 2) t.q.x++; else t.q.y++; }
+}
+
+// TestField.cpp:261-278 reverseWallkick
+TE_HD bool probe_reverse_kick(const Ctx& cx, Probe& t) {
+    if (t.q.kind == 6) return false;
+    if (probe_shift(cx, t, +1)) { probe_shift(cx, t, -1); return false; }
+    if (probe_shift(cx, t, -1)) { probe_shift(cx, t, +1); return false; }
+    const Pose here = pose_get(t);
+    if (probe_wallkick(cx, t)) { pose_set(t, here); return true; }
+    if (t.q.kind == 2 || t.q.kind == 3 || t.q.kind == 4) {
+        probe_flip_keep_pos(t);
+        bool ok = probe_wallkick(cx, t);
+        pose_set(t, here);
+        return ok;
+    }
+    pose_set(t, here);
+    return false;
+}
+
+// TestField.cpp:189-200 finesseIsPossible
+TE_HD bool probe_reachable(const Ctx& cx, Probe& t) {
+    const Pose here = pose_get(t);
+    if (probe_reverse_kick(cx, t)) { pose_set(t, here); return true; }
+    pose_set(t, here);
+    if (probe_slide(cx, t, -1, true)) { pose_set(t, here); return true; }
+    bool ok = probe_slide(cx, t, +1, true);
+    pose_set(t, here);
+    return ok;
+}
+
+// TestField.cpp:113-125 findNextMove + :174-187 tryAllFinesseMoves + :127-164 useFinesseMove
+TE_HD void probe_column(const Ctx& cx, Probe& t) {
+    int n = 0;
+    emit_rotation(t, n, t.q.rot - t.spawn);
+    emit_start_moves(t, n, t.q.x);
+    emit_key(t, n, 7);
+    emit_end(t, n);
+    probe_drop(cx, t);
+    const Pose landed = pose_get(t);
+    for (int y = landed.y + 2; y < cx.H - 1; y++) {
+        pose_set(t, landed);
+        t.q.y = y;
+        if (probe_fits(cx, t)) {
+            probe_drop(cx, t);
+            y = t.q.y;
+            if (probe_reachable(cx, t)) {
+                n = 0;
+                emit_rotation(t, n, t.best_rot - t.spawn);
+                emit_start_moves(t, n, t.best_x);
+                for (int i = t.best_len - 1; i >= 0; i--) {
+                    int v = t.best[i];
+                    if (v < 240) for (int k = 0; k < v; k++) emit_key(t, n, 252);
+                    else emit_key(t, n, v);
+                }
+                emit_key(t, n, 7);
+                emit_end(t, n);
+            }
+        }
+    }
+    pose_set(t, landed);
+}
+
 // ---------------------------------------------------------------- the two-phase step
 
 // PythonHandle.cpp:124-136 distributeLines

@@ -87,6 +87,15 @@ __global__ __launch_bounds__(256) void k_enumerate(const uint32_t* state, int n_
     if (t < (size_t)n * 40) enumerate_body<P>(state, n_games, t, idx, player, H, d_shape_table.s, valid, land_y, cleared, after);
 }
 
+template <int P>
+__global__ __launch_bounds__(64) void k_actions(const uint32_t* state, int n_games, int n, const int32_t* idx, const uint8_t* player,
+                                                int H, uint8_t* count, uint8_t* lens, uint8_t* keys, int max_lists, int max_keys,
+                                                uint32_t* status) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < (size_t)n * 40)
+        actions_body<P>(state, n_games, t, idx, player, H, d_shape_table.s, count, lens, keys, max_lists, max_keys, status);
+}
+
 __global__ __launch_bounds__(256) void k_snapshot(uint32_t* state, uint32_t* gstate, int n_games, int n, const int32_t* idx,
                                                   int P, uint32_t* blob, int restore) {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -258,6 +267,11 @@ static int finish_call(tetris_batch* b) {
     uint32_t st = *b->h_status;
     if (st & ST_STREAM_EXHAUSTED) return fail(TETRIS_E_STREAM, "an episode ran past the RNG tables; state is invalid");
     if (st & ST_FIFO_OVERFLOW) return fail(TETRIS_E_FIFO, "garbage FIFO overflow (> 8 pending packets); state is invalid");
+    if (st & ST_BAD_ARGUMENT) {
+        HIP_TRY(hipMemsetAsync(b->d_status, 0, 4, b->stream));
+        HIP_TRY(hipStreamSynchronize(b->stream));
+        return fail(TETRIS_E_ARG, "output capacity exceeded (max_lists / max_keys too small)");
+    }
     if (st & ST_NEED_EXTEND) {
         std::lock_guard<std::mutex> lock(g_tab_mutex);
         int rc = tables_extend(b->tab, b->stream);
@@ -651,6 +665,69 @@ int tetris_enumerate_drops(tetris_batch* b, const int32_t* idx, int n, const uin
     memcpy(valid, b->s_out0.h, lanes); memcpy(land_y, b->s_out1.h, lanes); memcpy(cleared, b->s_out2.h, lanes);
     if (after) memcpy(after, b->s_big.h, lanes * NCOL * 4);
     return TETRIS_OK;
+}
+
+int tetris_get_actions(tetris_batch* b, const int32_t* idx, int n, const uint8_t* player, uint8_t* keys, uint8_t* lens,
+                       int32_t* count, int max_lists, int max_keys) {
+    int rc = check_batch(b);
+    if (rc) return rc;
+    if (!keys || !lens || !count || max_lists < 1 || max_keys < 1 || max_keys > 255) return fail(TETRIS_E_ARG, "keys/lens/count/max_*");
+    if (n < 0 || (!idx && n > b->N)) return fail(TETRIS_E_ARG, "n out of range");
+    if (player)
+        for (int i = 0; i < n; i++)
+            if (player[i] >= b->P) return fail(TETRIS_E_ARG, "player index out of range");
+    const int LANE_LISTS = 16;                       // lists one (x, rotation) start can produce (<= H/2)
+    const int CHUNK_GAMES = 1024;                    // bounds the staging buffers
+    Stage s_cnt, s_len, s_key;
+    int result = TETRIS_OK;
+    for (int g0 = 0; g0 < n && result == TETRIS_OK; g0 += CHUNK_GAMES) {
+        const int m = (n - g0 < CHUNK_GAMES) ? n - g0 : CHUNK_GAMES;
+        const size_t lanes = (size_t)m * 40;
+        const int32_t* d_idx = nullptr;
+        std::vector<int32_t> ident;
+        const int32_t* h_idx = idx ? idx + g0 : nullptr;
+        if (!h_idx && g0 > 0) { ident.resize(m); for (int i = 0; i < m; i++) ident[i] = g0 + i; h_idx = ident.data(); }
+        if ((rc = stage_idx(b, h_idx, m, &d_idx))) { result = rc; break; }
+        const uint8_t* d_player = nullptr;
+        if (player) {
+            if ((rc = stage_in(b, b->s_in0, player + g0, (size_t)m))) { result = rc; break; }
+            d_player = (const uint8_t*)b->s_in0.d;
+        }
+        if ((rc = s_cnt.ensure(lanes + 4)) || (rc = s_len.ensure(lanes * LANE_LISTS + 4)) ||
+            (rc = s_key.ensure(lanes * LANE_LISTS * max_keys + 4))) { result = rc; break; }
+        dim3 grid((unsigned)((lanes + 63) / 64)), block(64);
+        if (b->P == 1)
+            hipLaunchKernelGGL(k_actions<1>, grid, block, 0, b->stream, b->d_state, b->N, m, d_idx, d_player, b->H, (uint8_t*)s_cnt.d,
+                               (uint8_t*)s_len.d, (uint8_t*)s_key.d, LANE_LISTS, max_keys, b->d_status);
+        else
+            hipLaunchKernelGGL(k_actions<2>, grid, block, 0, b->stream, b->d_state, b->N, m, d_idx, d_player, b->H, (uint8_t*)s_cnt.d,
+                               (uint8_t*)s_len.d, (uint8_t*)s_key.d, LANE_LISTS, max_keys, b->d_status);
+        if (hipGetLastError() != hipSuccess) { result = fail(TETRIS_E_HIP, "k_actions launch failed"); break; }
+        (void)hipMemcpyAsync(s_cnt.h, s_cnt.d, lanes, hipMemcpyDeviceToHost, b->stream);
+        (void)hipMemcpyAsync(s_len.h, s_len.d, lanes * LANE_LISTS, hipMemcpyDeviceToHost, b->stream);
+        (void)hipMemcpyAsync(s_key.h, s_key.d, lanes * LANE_LISTS * max_keys, hipMemcpyDeviceToHost, b->stream);
+        if ((rc = finish_call(b))) { result = rc; break; }
+        const uint8_t* hc = (const uint8_t*)s_cnt.h;
+        const uint8_t* hl = (const uint8_t*)s_len.h;
+        const uint8_t* hk = (const uint8_t*)s_key.h;
+        for (int i = 0; i < m && result == TETRIS_OK; i++) {
+            int total = 0;
+            for (int xi = 0; xi < 10; xi++)               // the reference enumerates x-major, rotation-minor
+                for (int r = 0; r < 4; r++) {
+                    const size_t lane = (size_t)i * 40 + r * 10 + xi;
+                    for (int k = 0; k < hc[lane]; k++) {
+                        if (total >= max_lists) { result = fail(TETRIS_E_ARG, "more than max_lists key lists for one game"); break; }
+                        const int len = hl[lane * LANE_LISTS + k];
+                        lens[(size_t)(g0 + i) * max_lists + total] = (uint8_t)len;
+                        memcpy(keys + ((size_t)(g0 + i) * max_lists + total) * max_keys, hk + (lane * LANE_LISTS + k) * max_keys, (size_t)len);
+                        total++;
+                    }
+                }
+            count[g0 + i] = total;
+        }
+    }
+    s_cnt.release(); s_len.release(); s_key.release();
+    return result;
 }
 
 int tetris_rollout_random(tetris_batch* b, int launches, int steps_per_launch, uint32_t policy_seed, uint64_t first_step,

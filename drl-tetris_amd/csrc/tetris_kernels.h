@@ -269,6 +269,40 @@ TE_HD void enumerate_body(const uint32_t* state, int n_games, size_t t, const in
     cleared[t] = (uint8_t)gone;
 }
 
+// PythonHandle.cpp:190 get_actions -> TestField.cpp:64-111 getMask(2): lane t = (game i, rotation r, column xi);
+// slab of lane t: count[t], lens[t][max_lists], keys[t][max_lists][max_keys]
+template <int P>
+TE_HD void actions_body(const uint32_t* state, int n_games, size_t t, const int32_t* idx, const uint8_t* player, int H,
+                        const uint32_t* shapes, uint8_t* count, uint8_t* lens, uint8_t* keys, int max_lists, int max_keys,
+                        uint32_t* status) {
+    const int i = (int)(t / 40), j = (int)(t % 40), r = j / 10, xi = j % 10;
+    const size_t slot = idx ? (size_t)idx[i] : (size_t)i;
+    const int p = player ? player[i] : 0;
+    const size_t ws = (size_t)P * n_games;
+    const uint32_t* s = state + (size_t)p * n_games + slot;
+    Probe pr;
+    for (int c = 0; c < NCOL; c++) pr.q.col[c] = s[(size_t)(W_COL0 + c) * ws];
+    const uint32_t w = s[(size_t)W_PIECE * ws];
+    const int kind = w & 7, cur_rot = (w >> 3) & 3;
+    Ctx cx;
+    cx.shapes = shapes; cx.H = H; cx.floor_bits = ~0u << H;
+    const int n_rot = kind == 6 ? 1 : (kind == 4 || kind == 2 || kind == 3) ? 2 : 4;
+    pr.q.kind = kind; pr.q.rot = kind == 6 ? cur_rot : r; pr.q.x = xi - 1; pr.q.y = 0;
+    pr.spawn = spawn_rot(kind);
+    pr.path_len = 0; pr.best_len = 0; pr.best_x = 0; pr.best_rot = 0;
+    pr.keys = keys + t * (size_t)max_lists * max_keys; pr.lens = lens + t * (size_t)max_lists;
+    pr.max_lists = max_lists; pr.max_keys = max_keys; pr.n_lists = 0; pr.overflow = 0;
+    if (kind <= 6 && r < n_rot && pr.q.x <= NCOL - 2 && probe_fits(cx, pr)) probe_column(cx, pr);
+    count[t] = (uint8_t)imin(pr.n_lists, 255);
+    if (pr.overflow || pr.n_lists > max_lists) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        atomicOr(status, (uint32_t)ST_BAD_ARGUMENT);
+#else
+        *status |= ST_BAD_ARGUMENT;
+#endif
+    }
+}
+
 // per-game cumulative rollout counters of one game -> {episodes, lines, sent}
 TE_HD void totals_of_game(const uint32_t* gstate, int n_games, int i, unsigned long long out[3]) {
     out[0] = gstate[(size_t)G_EPISODE * n_games + i];

@@ -125,6 +125,15 @@ int tetris_set_dead(tetris_batch *b, const int32_t *idx, int n, const uint8_t *d
 int tetris_enumerate_drops(tetris_batch *b, const int32_t *idx, int n, const uint8_t *player, uint8_t *valid,
                            int8_t *land_y, uint8_t *cleared, uint32_t *after);
 
+/* replaces: PythonHandle.get_actions(player); masks[player].action (PythonHandle.cpp:190, TestField.cpp:64-415):
+ * the reference's exact ordered key lists of the "place_block" action type — every (x, rotation) drop plus the
+ * tuck / spin placements found by its backwards search — for the current piece of player[i] (NULL = player 0).
+ * count[n] = number of lists; list k of game i: lens[i][k] keys at keys[i][k][0..].  Python applies
+ * data_types.action_list (dedupe, null-move policy) on top.  TETRIS_E_ARG if a game has more than max_lists lists
+ * or a list more than max_keys keys (64 / 48 always suffice for 10-wide boards up to 31 rows).                   */
+int tetris_get_actions(tetris_batch *b, const int32_t *idx, int n, const uint8_t *player, uint8_t *keys,
+                       uint8_t *lens, int32_t *count, int max_lists, int max_keys);
+
 /* Built-in synthetic rollout = the worker loop of drl_tetris/worker.py:91-118 with a random policy
  * (SURVEY.md §8d): per env-step  Philox4x32-10(policy_seed; game, step) -> (r = w0 & 3,
  * t = w1 mod 10), acting player = step mod P, perform_action, auto-reset of finished games with

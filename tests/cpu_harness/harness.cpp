@@ -275,6 +275,35 @@ int tetris_enumerate_drops(tetris_batch* b, const int32_t* idx, int n, const uin
     return TETRIS_OK;
 }
 
+int tetris_get_actions(tetris_batch* b, const int32_t* idx, int n, const uint8_t* player, uint8_t* keys, uint8_t* lens, int32_t* count,
+                       int max_lists, int max_keys) {
+    int rc = check_idx(b, idx, n); if (rc) return rc;
+    const int LANE_LISTS = 16;
+    const size_t lanes = (size_t)n * 40;
+    std::vector<uint8_t> hc(lanes), hl(lanes * LANE_LISTS), hk(lanes * LANE_LISTS * max_keys);
+    for (size_t t = 0; t < lanes; t++) {
+        if (b->P == 1) actions_body<1>(b->state.data(), b->N, t, idx, player, b->H, SHAPES.s, hc.data(), hl.data(), hk.data(), LANE_LISTS, max_keys, &b->status);
+        else actions_body<2>(b->state.data(), b->N, t, idx, player, b->H, SHAPES.s, hc.data(), hl.data(), hk.data(), LANE_LISTS, max_keys, &b->status);
+    }
+    if (b->status & ST_BAD_ARGUMENT) { b->status &= ~(uint32_t)ST_BAD_ARGUMENT; return fail(TETRIS_E_ARG, "output capacity exceeded"); }
+    for (int i = 0; i < n; i++) {
+        int total = 0;
+        for (int xi = 0; xi < 10; xi++)
+            for (int r = 0; r < 4; r++) {
+                const size_t lane = (size_t)i * 40 + r * 10 + xi;
+                for (int k = 0; k < hc[lane]; k++) {
+                    if (total >= max_lists) return fail(TETRIS_E_ARG, "more than max_lists key lists for one game");
+                    const int len = hl[lane * LANE_LISTS + k];
+                    lens[(size_t)i * max_lists + total] = (uint8_t)len;
+                    memcpy(keys + ((size_t)i * max_lists + total) * max_keys, hk.data() + (lane * LANE_LISTS + k) * max_keys, (size_t)len);
+                    total++;
+                }
+            }
+        count[i] = total;
+    }
+    return TETRIS_OK;
+}
+
 int tetris_rollout_random(tetris_batch* b, int launches, int steps_per_launch, uint32_t policy_seed, uint64_t first_step, int ms,
                           uint64_t counters[4], float* elapsed_ms) {
     if (launches < 1 || steps_per_launch < 0 || steps_per_launch > 256) return fail(TETRIS_E_ARG, "launches/steps_per_launch");

@@ -17,5 +17,5 @@ def test_engine_replays_reference_trace(kind, name):
     def factory(P, H, W, pieces, seed):
         return engines.make(kind, 1, P, H, pieces, seeds=seed)
 
-    n = replay.replay(trace, factory, fields=FIELDS, occupancy_only=True, max_events=max_events)
+    n = replay.replay(trace, factory, fields=FIELDS, occupancy_only=True, max_events=max_events, check_actions=True)
     assert n > 0

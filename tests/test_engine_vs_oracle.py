@@ -199,3 +199,35 @@ def test_enumerate_drops_matches_oracle(kind):
     v1, y1, c1, _ = eng.enumerate_drops(idx=sub, player=1, columns=False)
     v2, y2, c2, _ = ref.enumerate_drops(idx=sub, player=1, cells=False)
     assert np.array_equal(v1, v2) and np.array_equal(y1, y2) and np.array_equal(c1, c2)
+
+
+@pytest.mark.parametrize("kind", engines.ENGINE_PARAMS)
+def test_get_actions_matches_oracle(kind):
+    """Exact ordered key lists of PythonHandle.get_actions (TestField.cpp:64-415) on batches of mid-game boards,
+    including boards with overhangs (the games are played with enumerated tuck/spin actions)."""
+    n, P = (1024 if kind == "hip" else 96), 2
+    eng, ref = _pair(kind, n, P, seed_base=7000)
+    rng = np.random.default_rng(21)
+    K = 48
+    tucks = 0
+    for s in range(14):
+        player = np.full(n, s % 2, np.uint8)
+        lists = eng.get_actions(player=player)
+        for g in range(0, n, max(1, n // 48)):
+            want = ref.get_actions(g, s % 2)
+            assert lists[g] == want, (s, g)
+        tucks += sum(1 for l in lists for a in l if 5 in a or 6 in a)
+        keys = np.zeros((n, P, K), np.uint8)
+        lens = np.ones((n, P), np.uint8)
+        for g in range(n):
+            a = lists[g][int(rng.integers(len(lists[g])))]
+            keys[g, s % 2, : len(a)] = a
+            lens[g, s % 2] = len(a)
+        d1, _, _ = eng.step_keys(keys, lens)
+        ref.make_actions(keys, lens)
+        d2 = ref.finish_actions(400)
+        assert np.array_equal(d1, d2)
+    assert tucks > 0
+    engines.assert_same_state(eng, ref, where="after playing enumerated actions")
+    sub = np.array([3, 1, 7], np.int32)
+    assert eng.get_actions(sub, player=[1, 0, 1]) == [ref.get_actions(3, 1), ref.get_actions(1, 0), ref.get_actions(7, 1)]

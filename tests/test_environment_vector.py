@@ -151,3 +151,38 @@ def test_action_list_and_rewards_follow_the_reference_types():
     assert float(edt.maingoal_reward([-1])()) == -1.0
     with pytest.raises(AssertionError):
         edt.action((1, 2))
+
+
+@pytest.mark.parametrize("kind", engines.ENGINE_PARAMS)
+def test_get_actions_simulate_all_and_random_action(kind):
+    """sherlock-style use (agents/sherlock_agent/sherlock_agent.py:94-120): enumerate, simulate all afterstates without
+    finalizing, pick one, perform it."""
+    n, P = 5, 2
+    pkg, env_mod, env = _make_env(kind, n, {"n_players": P, "game_size": [20, 10], "seed_source": _Clock(300)})
+    edt = __import__("importlib").import_module("drl-tetris_amd.data_types")
+    ref = orc.OracleBatch(n, P, 20, 10, seeds=301)
+    ref.reset(seeds=302)
+    np.random.seed(0)
+    for it in range(8):
+        p = it % 2
+        al = env.get_actions(player=p)
+        assert len(al) == n and all(isinstance(x, edt.action_list) for x in al)
+        for i in range(n):
+            want = edt.action_list(ref.get_actions(i, p), remove_null=True)        # bar_null_moves default True
+            assert [list(a) for a in al[i]] == [list(a) for a in want]
+        sims = env.simulate_all_actions(player=p, finalize=False)
+        assert [len(s) for s in sims] == [len(a) for a in al]
+        # every simulated afterstate differs from the current board by exactly one stamped piece (4 cells)
+        cur = env.get_state()
+        for i in range(n):
+            base = cur[i].backend_state.states[p].field > 0
+            for st in sims[i]:
+                assert int(((st.backend_state.states[p].field > 0) ^ base).sum()) == 4
+        acts = env.get_random_action(player=p)
+        env.perform_action(acts, player=p)
+        keys = np.zeros((n, P, 48), np.uint8); lens = np.ones((n, P), np.uint8)
+        for i, a in enumerate(acts):
+            keys[i, p, : len(a)] = a; lens[i, p] = len(a)
+        ref.make_actions(keys, lens); ref.finish_actions(400)
+    a, b = env.backend.observe()[0], ref.observe()[0]
+    assert np.array_equal(a["field"] > 0, b["field"] > 0) and np.array_equal(a["next"], b["next"])
