@@ -64,6 +64,8 @@ _SIGNATURES = {
     "tetris_set_dead": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "tetris_enumerate_drops": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "tetris_get_actions": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    "tetris_observe_packed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "tetris_observe_packed_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "tetris_rollout_random": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_uint32, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p]),
     "tetris_device_state": (C.c_void_p, [C.c_void_p]),
     "tetris_stream": (C.c_void_p, [C.c_void_p]),
@@ -190,6 +192,18 @@ class TetrisBatch:
         lw = np.zeros(n, np.int8)
         self._check(self.lib.tetris_observe_records(self._h, _p(a), n, _p(rec), _p(ro), _p(lw)))
         return rec, ro, lw
+
+    def observe_packed(self, idx=None, player=None):
+        """NN-ready observations (state_dict + unpacker defaults): visual u8 [S,n,H,W], vector u8 [S,n,12], piece u8 [S,n];
+        slot 0 = `player`'s own board, slot 1 = the opponent's."""
+        a, n = self._idx(idx)
+        pl = None if player is None else _u8(np.broadcast_to(player, (n,)))
+        S = self.n_players
+        visual = np.zeros((S, n, self.height, self.width), np.uint8)
+        vector = np.zeros((S, n, 12), np.uint8)
+        piece = np.zeros((S, n), np.uint8)
+        self._check(self.lib.tetris_observe_packed(self._h, _p(a), n, _p(pl), _p(visual), _p(vector), _p(piece)))
+        return visual, vector, piece
 
     def snapshot(self, idx=None):
         a, n = self._idx(idx)

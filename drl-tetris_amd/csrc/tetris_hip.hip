@@ -79,6 +79,43 @@ __global__ __launch_bounds__(256) void k_observe(const uint32_t* state, const ui
     if (i < n) observe_body<P>(state, gstate, n_games, i, idx, H, d_shape_table.s, rec, round_over, last_winner);
 }
 
+// Observation kernel: one lane reads its board's ten column words (coalesced SoA), expands them to H*10 bytes
+// in LDS; after a barrier the workgroup streams its 256 boards' planes out as ONE contiguous run of dwords, so the
+// uint8 rows leave the chip fully coalesced (a lane writing its own 200 bytes would not be).
+template <int P>
+__global__ __launch_bounds__(256) void k_observe_packed(const uint32_t* state, int n_games, int n, const int32_t* idx,
+                                                        const uint8_t* player, int H, uint8_t* visual, uint8_t* vector,
+                                                        uint8_t* piece) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_cells[];      // 256 * H * 10 bytes
+    const int cells = H * NCOL;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int first = blockIdx.x * 256;
+    const int nb = (n - first < 256) ? n - first : 256;
+    for (int sl = 0; sl < P; sl++) {
+        if (i < n) {
+            const size_t slot = idx ? (size_t)idx[i] : (size_t)i;
+            const int me = player ? player[i] : 0;
+            const int p = (sl == 0) ? me : (P - 1 - me);
+            uint8_t vec[12];
+            const int kind = observe_board(state, n_games, slot, P, p, H, s_cells + (size_t)threadIdx.x * cells, vec);
+            uint8_t* v = vector + ((size_t)sl * n + i) * 12;
+            for (int k = 0; k < 12; k++) v[k] = vec[k];
+            piece[(size_t)sl * n + i] = (uint8_t)kind;
+        }
+        __syncthreads();
+        uint8_t* out = visual + ((size_t)sl * n + first) * cells;
+        const size_t bytes = (size_t)nb * cells;
+        if ((((uintptr_t)out | bytes) & 3u) == 0) {
+            const uint32_t* src = (const uint32_t*)s_cells;
+            uint32_t* dst = (uint32_t*)out;
+            for (size_t k = threadIdx.x; k < bytes / 4; k += 256) dst[k] = src[k];
+        } else {
+            for (size_t k = threadIdx.x; k < bytes; k += 256) out[k] = s_cells[k];
+        }
+        __syncthreads();
+    }
+}
+
 template <int P>
 __global__ __launch_bounds__(256) void k_enumerate(const uint32_t* state, int n_games, int n, const int32_t* idx,
                                                    const uint8_t* player, int H, uint8_t* valid, int8_t* land_y,
@@ -582,6 +619,55 @@ int tetris_observe_records(tetris_batch* b, const int32_t* idx, int n, tetris_re
     if (records) memcpy(records, b->s_big.h, rec_bytes);
     if (round_over) memcpy(round_over, b->s_out0.h, (size_t)n);
     if (last_winner) memcpy(last_winner, b->s_out1.h, (size_t)n);
+    return TETRIS_OK;
+}
+
+int tetris_observe_packed_dev(tetris_batch* b, const int32_t* d_idx, int n, const uint8_t* d_player, uint8_t* d_visual,
+                              uint8_t* d_vector, uint8_t* d_piece) {
+    int rc = check_batch(b);
+    if (rc) return rc;
+    if (!d_visual || !d_vector || !d_piece) return fail(TETRIS_E_ARG, "visual/vector/piece are NULL");
+    if (n < 0 || (!d_idx && n > b->N)) return fail(TETRIS_E_ARG, "n out of range");
+    if (n == 0) return TETRIS_OK;
+    dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    const size_t lds = (size_t)256 * b->H * NCOL;
+    if (lds > 48 * 1024) {      // up to 79 KB of the CU's 160 KB for 31-row boards
+        const void* fn = b->P == 1 ? (const void*)k_observe_packed<1> : (const void*)k_observe_packed<2>;
+        HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    if (b->P == 1)
+        hipLaunchKernelGGL(k_observe_packed<1>, grid, block, lds, b->stream, b->d_state, b->N, n, d_idx, d_player, b->H, d_visual,
+                           d_vector, d_piece);
+    else
+        hipLaunchKernelGGL(k_observe_packed<2>, grid, block, lds, b->stream, b->d_state, b->N, n, d_idx, d_player, b->H, d_visual,
+                           d_vector, d_piece);
+    HIP_TRY(hipGetLastError());
+    return TETRIS_OK;
+}
+
+int tetris_observe_packed(tetris_batch* b, const int32_t* idx, int n, const uint8_t* player, uint8_t* visual, uint8_t* vector,
+                          uint8_t* piece) {
+    int rc = check_batch(b);
+    if (rc) return rc;
+    if (!visual || !vector || !piece) return fail(TETRIS_E_ARG, "visual/vector/piece are NULL");
+    const int32_t* d_idx;
+    if ((rc = stage_idx(b, idx, n, &d_idx))) return rc;
+    if (n == 0) return TETRIS_OK;
+    const uint8_t* d_player = nullptr;
+    if (player) {
+        for (int i = 0; i < n; i++)
+            if (player[i] >= b->P) return fail(TETRIS_E_ARG, "player index out of range");
+        if ((rc = stage_in(b, b->s_in0, player, (size_t)n))) return rc;
+        d_player = (const uint8_t*)b->s_in0.d;
+    }
+    const size_t vis = (size_t)b->P * n * b->H * NCOL, vec = (size_t)b->P * n * 12, pc = (size_t)b->P * n;
+    if ((rc = b->s_big.ensure(vis + 16)) || (rc = b->s_out0.ensure(vec + 4)) || (rc = b->s_out1.ensure(pc + 4))) return rc;
+    if ((rc = tetris_observe_packed_dev(b, d_idx, n, d_player, (uint8_t*)b->s_big.d, (uint8_t*)b->s_out0.d, (uint8_t*)b->s_out1.d))) return rc;
+    HIP_TRY(hipMemcpyAsync(b->s_big.h, b->s_big.d, vis, hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipMemcpyAsync(b->s_out0.h, b->s_out0.d, vec, hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipMemcpyAsync(b->s_out1.h, b->s_out1.d, pc, hipMemcpyDeviceToHost, b->stream));
+    if ((rc = finish_call(b))) return rc;
+    memcpy(visual, b->s_big.h, vis); memcpy(vector, b->s_out0.h, vec); memcpy(piece, b->s_out1.h, pc);
     return TETRIS_OK;
 }
 

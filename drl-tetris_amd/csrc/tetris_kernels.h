@@ -235,6 +235,26 @@ TE_HD void observe_body(const uint32_t* state, const uint32_t* gstate, int n_gam
     }
 }
 
+// state_dict + unpacker for one player-board (state_processors.py:23-54, state_unpack.py:88-137):
+// `cells` receives H*10 bytes (field > 0, row-major), `vec` 12 bytes, returns the piece index
+TE_HD int observe_board(const uint32_t* state, int n_games, size_t slot, int P, int p, int H, uint8_t* cells, uint8_t* vec) {
+    const size_t ws = (size_t)P * n_games;
+    const uint32_t* s = state + (size_t)p * n_games + slot;
+    uint32_t col[NCOL];
+    for (int c = 0; c < NCOL; c++) col[c] = s[(size_t)(W_COL0 + c) * ws];
+    for (int y = 0; y < H; y++)
+        for (int c = 0; c < NCOL; c++) cells[y * NCOL + c] = (uint8_t)((col[c] >> y) & 1u);
+    const uint32_t w = s[(size_t)W_PIECE * ws];
+    const uint32_t m = s[(size_t)W_MISC * ws];
+    const uint32_t dc = s[(size_t)W_DROPCOMBO * ws];
+    const int x = (int)((w >> 5) & 15) - 4, y = (w >> 9) & 31, next = (w >> 14) & 7;
+    uint32_t t = ((dc >> 16) + 50u) & 0xFFFFu;            // uint16 array + 50 wraps like numpy (state_processors.py:38)
+    if (t > 25000u) t = 25000u;
+    vec[0] = (uint8_t)x; vec[1] = (uint8_t)y; vec[2] = (uint8_t)(m & 255); vec[3] = (uint8_t)(t / 100u); vec[4] = (uint8_t)((m >> 8) & 255);
+    for (int k = 0; k < 7; k++) vec[5 + k] = (uint8_t)(next == k);
+    return (int)(w & 7);
+}
+
 // TestField.cpp:64-125 (drop placements): lane t = (game i, rotation r, column index xi)
 template <int P>
 TE_HD void enumerate_body(const uint32_t* state, int n_games, size_t t, const int32_t* idx, const uint8_t* player, int H,

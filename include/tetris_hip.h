@@ -107,6 +107,19 @@ int tetris_step_rt_dev(tetris_batch *b, const uint8_t *d_rot, const uint8_t *d_t
 int tetris_observe_records(tetris_batch *b, const int32_t *idx, int n, tetris_record *records,
                            uint8_t *round_over, int8_t *last_winner);
 
+/* replaces: state_processors.state_dict + agent_utils/state_unpack.unpacker in its default SVENton configuration
+ * (state_processors.py:23-54; state_unpack.py:88-137: observation_mode 'separate', player_mode 'separate',
+ * separate_piece): NN-ready observations written by one kernel.  Slot 0 = the board of player[i] ("me"), slot 1 = the
+ * opponent (only when n_players == 2).  All outputs uint8:
+ *   visual [S][n][H][W]  field > 0
+ *   vector [S][n][12]    x, y, inc_lines, min(25000, combo_time + 50) / 100, combo_count, nextpiece one-hot (7)
+ *   piece  [S][n]        index of the current piece (state_dict "piece_idx")
+ * Host pointers (synchronous); the _dev variant takes device pointers and only enqueues.                          */
+int tetris_observe_packed(tetris_batch *b, const int32_t *idx, int n, const uint8_t *player, uint8_t *visual,
+                          uint8_t *vector, uint8_t *piece);
+int tetris_observe_packed_dev(tetris_batch *b, const int32_t *d_idx, int n, const uint8_t *d_player,
+                              uint8_t *d_visual, uint8_t *d_vector, uint8_t *d_piece);
+
 /* replaces: PythonHandle.copy() / .set() (PythonHandle.cpp:36-42): exact state incl. RNG position.
  * blob[n][tetris_snapshot_words()] uint32 (host).  Blobs move between batches of equal geometry
  * and piece map.                                                                                 */

@@ -304,6 +304,23 @@ int tetris_get_actions(tetris_batch* b, const int32_t* idx, int n, const uint8_t
     return TETRIS_OK;
 }
 
+int tetris_observe_packed(tetris_batch* b, const int32_t* idx, int n, const uint8_t* player, uint8_t* visual, uint8_t* vector,
+                          uint8_t* piece) {
+    int rc = check_idx(b, idx, n); if (rc) return rc;
+    const int cells = b->H * NCOL;
+    for (int sl = 0; sl < b->P; sl++)
+        for (int i = 0; i < n; i++) {
+            size_t slot = idx ? (size_t)idx[i] : (size_t)i;
+            int me = player ? player[i] : 0;
+            int p = sl == 0 ? me : b->P - 1 - me;
+            piece[(size_t)sl * n + i] = (uint8_t)observe_board(b->state.data(), b->N, slot, b->P, p, b->H,
+                                                               visual + ((size_t)sl * n + i) * cells, vector + ((size_t)sl * n + i) * 12);
+        }
+    return TETRIS_OK;
+}
+int tetris_observe_packed_dev(tetris_batch* b, const int32_t* idx, int n, const uint8_t* player, uint8_t* visual, uint8_t* vector,
+                              uint8_t* piece) { return tetris_observe_packed(b, idx, n, player, visual, vector, piece); }
+
 int tetris_rollout_random(tetris_batch* b, int launches, int steps_per_launch, uint32_t policy_seed, uint64_t first_step, int ms,
                           uint64_t counters[4], float* elapsed_ms) {
     if (launches < 1 || steps_per_launch < 0 || steps_per_launch > 256) return fail(TETRIS_E_ARG, "launches/steps_per_launch");

@@ -231,3 +231,35 @@ def test_get_actions_matches_oracle(kind):
     engines.assert_same_state(eng, ref, where="after playing enumerated actions")
     sub = np.array([3, 1, 7], np.int32)
     assert eng.get_actions(sub, player=[1, 0, 1]) == [ref.get_actions(3, 1), ref.get_actions(1, 0), ref.get_actions(7, 1)]
+
+
+@pytest.mark.parametrize("kind", engines.ENGINE_PARAMS)
+@pytest.mark.parametrize("P,H", [(2, 20), (1, 22), (2, 21), (1, 31)])
+def test_observe_packed_matches_state_dict(kind, P, H):
+    """The observation kernel against state_dict + unpacker semantics computed from oracle records
+    (state_processors.py:23-54; state_unpack.py:88-137), from each player's perspective."""
+    n = 3000 if kind == "hip" else 300
+    eng, ref = _pair(kind, n, P, H, seed_base=99)
+    rng = np.random.default_rng(2)
+    for s in range(40):
+        rot, trans = rng.integers(0, 4, n).astype(np.uint8), rng.integers(0, 10, n).astype(np.uint8)
+        eng.step_rt(rot, trans, s % P)
+        ref.step_rt(rot, trans, s % P)
+    rec = ref.observe()[0]
+    for trial in range(2):
+        me = rng.integers(0, P, n).astype(np.uint8)
+        idx = None if trial == 0 else np.sort(rng.choice(n, n // 3, replace=False)).astype(np.int32)
+        sel = np.arange(n) if idx is None else idx
+        visual, vector, piece = eng.observe_packed(idx, me[sel])
+        assert visual.shape == (P, len(sel), H, 10) and vector.shape == (P, len(sel), 12)
+        for sl in range(P):
+            who = me[sel] if sl == 0 else (P - 1 - me[sel])
+            r = rec[sel, who]
+            assert np.array_equal(visual[sl], (r["field"][:, :H, :] > 0).astype(np.uint8))
+            want = np.zeros((len(sel), 12), np.uint8)
+            want[:, 0] = r["x"].astype(np.uint8); want[:, 1] = r["y"].astype(np.uint8); want[:, 2] = r["inc_count"]
+            want[:, 3] = np.minimum(25000, (r["combo_remaining"].astype(np.uint32) + 50) & 0xFFFF) // 100
+            want[:, 4] = r["combo_count"]
+            want[np.arange(len(sel)), 5 + r["next"]] = 1
+            assert np.array_equal(vector[sl], want)
+            assert np.array_equal(piece[sl], r["piece"])
