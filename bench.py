@@ -113,46 +113,29 @@ def main():
         import torch
         import torch.distributed as dist
 
+        backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")     # "gloo" only to rehearse N>1 on a 1-GPU box
+        local_rank = local_rank % max(1, torch.cuda.device_count())
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     if args.gpus != world and rank == 0 and world > 1:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
 
-    pkg = ge.package()
+    ge.package()
+    import importlib
+    sharded = importlib.import_module("drl-tetris_amd.distributed")
     N, P, S = args.games, args.players, args.steps_per_launch
-    # rank r owns global games [r*N, (r+1)*N): distinct seed schedule per rank
-    seeds = None
-    from_game = rank * N
-    seeds = ((12345 + 7919 * (np.arange(N, dtype=np.int64) + from_game)) & 0xFFFF).astype(np.uint16).view(np.int16)
-    batch = pkg.TetrisBatch(N, P, args.height, 10, seeds=seeds, device=local_rank)
-    batch.set_game_offset(from_game)
-
-    def sync_all():
-        if dist is not None:
-            import torch
-            dist.barrier()
-            torch.cuda.synchronize()
-        batch.sync()
-
-    # warm-up (untimed)
-    first = 0
+    # rank r owns global games [r*N, (r+1)*N): distinct policy stream and seed schedule per rank, no collective
+    # on the data path; ShardedRollout brackets the timed launches with barrier + synchronize on both sides and
+    # reduces time (MAX) and counters (SUM) over the ranks.
+    shard = sharded.ShardedRollout(N, P, args.height, 10, rank=rank, world=world, device=local_rank, dist=dist)
     if args.warmup > 0:
-        batch.rollout_random(args.warmup, S, first_step=first)
-        first += args.warmup * S
-    sync_all()
-    t0 = time.perf_counter()
-    counters, ev_ms = batch.rollout_random(args.steps, S, first_step=first)
-    sync_all()
-    wall = time.perf_counter() - t0
-
-    if dist is not None:
-        import torch
-        t = torch.tensor([wall, ev_ms], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall, ev_ms = float(t[0]), float(t[1])
-        c = torch.tensor([int(x) for x in counters], dtype=torch.int64, device="cuda")
-        dist.all_reduce(c, op=dist.ReduceOp.SUM)
-        counters = c.cpu().numpy()
+        shard.run(args.warmup, S)                     # untimed warm-up
+    res = shard.run(args.steps, S)                    # exactly K timed launches
+    counters, wall, ev_ms = res["counters"], res["wall_s"], res["event_ms"]
+    batch = shard
 
     if rank == 0:
         env_steps = int(counters[0])

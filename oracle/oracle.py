@@ -97,6 +97,7 @@ def lib():
     L.or_set_dead.argtypes = [vp, vp, i32, vp]
     L.or_enumerate_drops.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp]
     L.or_rollout_random.argtypes = [vp, C.c_uint32, C.c_uint64, i32, i32, vp, vp, i32]
+    L.or_rollout_random_shard.argtypes = [vp, C.c_uint32, C.c_uint64, i32, i32, vp, vp, i32, C.c_uint32]
     L.or_mt19937_block.argtypes = [C.c_uint32, vp, i32]
     L.or_philox4x32_10.argtypes = [C.c_uint32] * 6 + [vp]
     L.or_combo_pow.restype = C.c_double
@@ -201,10 +202,10 @@ class OracleBatch:
         assert n <= max_lists
         return [keys[i, : lens[i]].tolist() for i in range(n)]
 
-    def rollout_random(self, steps, policy_seed=0xD71, first_step=0, ms=400, episode=None, threads=1):
+    def rollout_random(self, steps, policy_seed=0xD71, first_step=0, ms=400, episode=None, threads=1, game_offset=0):
         ep = np.zeros(self.n_games, np.uint32) if episode is None else episode
         counters = np.zeros(4, np.uint64)
-        self.L.or_rollout_random(self.h, policy_seed, first_step, steps, ms, _p(ep), _p(counters), threads)
+        self.L.or_rollout_random_shard(self.h, policy_seed, first_step, steps, ms, _p(ep), _p(counters), threads, game_offset)
         return ep, counters
 
 

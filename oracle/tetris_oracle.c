@@ -978,6 +978,11 @@ static int16_t episode_seed(int g, uint32_t e) {
 
 void or_rollout_random(or_batch *b, uint32_t policy_seed, uint64_t first_step, int steps, int ms,
                        uint32_t *episode, uint64_t counters[4], int threads) {
+    or_rollout_random_shard(b, policy_seed, first_step, steps, ms, episode, counters, threads, 0u);
+}
+
+void or_rollout_random_shard(or_batch *b, uint32_t policy_seed, uint64_t first_step, int steps, int ms,
+                             uint32_t *episode, uint64_t counters[4], int threads, uint32_t game_offset) {
     uint64_t n_steps = 0, n_episodes = 0, n_lines = 0, n_sent = 0;
 #ifdef _OPENMP
     if (threads < 1) threads = 1;
@@ -987,7 +992,7 @@ void or_rollout_random(or_batch *b, uint32_t policy_seed, uint64_t first_step, i
         for (int s = 0; s < steps; s++) {
             uint64_t step = first_step + (uint64_t)s;
             uint32_t w[4];
-            or_philox4x32_10(policy_seed, 0u, (uint32_t)g, (uint32_t)step, (uint32_t)(step >> 32), 0u, w);
+            or_philox4x32_10(policy_seed, 0u, game_offset + (uint32_t)g, (uint32_t)step, (uint32_t)(step >> 32), 0u, w);
             int r = (int)(w[0] & 3u), t = (int)(w[1] % 10u);
             int player = b->n_players > 1 ? (int)(step % (uint64_t)b->n_players) : 0;
             uint16_t sent_before = 0;
@@ -1004,7 +1009,7 @@ void or_rollout_random(or_batch *b, uint32_t policy_seed, uint64_t first_step, i
             if (done) {
                 n_episodes++;
                 episode[g]++;
-                reset_game(b, g, episode_seed(g, episode[g]));
+                reset_game(b, g, episode_seed((int)(game_offset + (uint32_t)g), episode[g]));
             }
         }
     }

@@ -139,6 +139,10 @@ void        or_enumerate_drops(const or_batch *b, const int32_t *idx, int n, con
 void        or_rollout_random(or_batch *b, uint32_t policy_seed, uint64_t first_step, int steps,
                               int ms, uint32_t *episode /*[N] in/out*/, uint64_t counters[4],
                               int threads);
+/* same, for a shard whose game 0 has global id `game_offset` (policy and seed schedule use global ids) */
+void        or_rollout_random_shard(or_batch *b, uint32_t policy_seed, uint64_t first_step, int steps,
+                                    int ms, uint32_t *episode, uint64_t counters[4], int threads,
+                                    uint32_t game_offset);
 
 /* Known-answer helpers                                                         */
 void        or_mt19937_block(uint32_t seed, uint32_t *out, int n);  /* first n tempered outputs */
