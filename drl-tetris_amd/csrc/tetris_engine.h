@@ -91,7 +91,7 @@ constexpr ShapeTable SHAPES = make_shape_table();
 struct Ctx {
     const uint32_t* shapes;          // 32 shape words (LDS on the GPU)
     const uint8_t* table;            // RNG table, one allocation: table[(chunk * 65536 + seed16) * 624 + r]
-    const uint8_t* first_ok;         // [65536]
+    const uint32_t* start;           // [65536] first_ok | piece(j) << 8 | piece(j+1) << 16 (tetris_tables.h)
     const double* combo_pow;         // [256] pow(c, 1.4 + 0.01 c) from the host libm (Combo.cpp:41)
     uint32_t n_draws;                // draws available per seed = n_chunks * 624
     uint32_t margin;                 // ST_NEED_EXTEND when a draw counter comes this close to n_draws
@@ -119,7 +119,7 @@ struct Player {
 };
 
 // table bytes a reset will need, fetched ahead of time (see prefetch_reset)
-struct ResetPrefetch { uint32_t seed16, first_ok, b0, b1; int ok; };
+struct ResetPrefetch { uint32_t seed16, word; int ok; };
 
 template <int P>
 struct Game {
@@ -536,13 +536,9 @@ TE_HD void restart_player(const Ctx& cx, Player& q, uint32_t seed16, uint32_t& s
     q.lines_sent = 0; q.lines_cleared = 0; q.garbage_cleared = 0;
     q.speedup_time = 0; q.drop_delay = 1000; q.drop_time = 0; q.lock_time = 0; q.lock_armed = 0;
     q.time_ms = 0; q.incoming = 0.0f; q.lines_seen = 0; q.dead = 0;
-    uint32_t j, b0, b1;
-    if (pf && pf->ok && pf->seed16 == seed16) { j = pf->first_ok; b0 = pf->b0; b1 = pf->b1; }
-    else {
-        j = cx.first_ok[seed16];
-        b0 = table_byte(cx, seed16, j, status);
-        b1 = table_byte(cx, seed16, j + 1, status);
-    }
+    (void)status;
+    const uint32_t word = (pf && pf->ok && pf->seed16 == seed16) ? pf->word : cx.start[seed16];
+    const uint32_t j = word & 0xFFu, b0 = (word >> 8) & 0xFFu, b1 = (word >> 16) & 0xFFu;
     q.kind = (int)(b0 & 7u);
     q.next = (int)(b1 & 7u);
     q.pf_ok = 0;
@@ -567,24 +563,13 @@ TE_HD void reset_game(const Ctx& cx, Game<P>& g, uint32_t seed16, const ResetPre
     for (int p = 0; p < P; p++) restart_player(cx, g.pl[p], g.seed16, g.status, pf);
 }
 
-// A game can only end this step if some board already reaches into its top rows: a locked piece adds
-// at most 4 rows, a garbage push 1.  For those games fetch what reset_game will read (first_ok, then
-// the first two dealt pieces) while the step itself is still computing.  A miss of this predictor
-// only costs latency: reset_game falls back to reading the tables itself.
-template <int P>
-TE_HD void prefetch_reset(const Ctx& cx, const Game<P>& g, uint32_t next_seed16, ResetPrefetch& pf) {
-    uint32_t top = 0;
-    TE_UNROLL
-    for (int p = 0; p < P; p++)
-        for (int c = 0; c < NCOL; c++) top |= g.pl[p].col[c];
-    pf.ok = 0; pf.seed16 = next_seed16 & 0xFFFFu; pf.first_ok = 0; pf.b0 = 0; pf.b1 = 0;
-    if (top & 0x3FFu) {
-        uint32_t st = 0;
-        pf.first_ok = cx.first_ok[pf.seed16];
-        pf.b0 = table_byte(cx, pf.seed16, pf.first_ok, st);
-        pf.b1 = table_byte(cx, pf.seed16, pf.first_ok + 1, st);
-        pf.ok = 1;
-    }
+// The rollout knows the seed of a game's NEXT episode one step ahead: read that seed's start word (one
+// independent 4-byte load from a 256 KB table that lives in L2) at the top of the step, so an auto-reset at the
+// bottom finds it in a register.  No load in the step depends on another load's result.
+TE_HD void prefetch_reset(const Ctx& cx, uint32_t next_seed16, ResetPrefetch& pf) {
+    pf.seed16 = next_seed16 & 0xFFFFu;
+    pf.word = cx.start[pf.seed16];
+    pf.ok = 1;
 }
 
 // PythonHandle.cpp:5-25 init: fresh GamePlay objects (nextpiece 0, reward 0, ...), restartRound, seed
@@ -605,12 +590,11 @@ TE_HD void init_game(const Ctx& cx, Game<P>& g, uint32_t seed16) {
 
 // gameField.cpp:55-103 rcw / rccw / r180 with the 7-offset kick test; turn = +1, +3 (ccw), +2.
 // `b0` must be band_window(q.y) on entry and is kept equal to band_window(q.y) on exit, so a run of
-// rotations and sideways moves at one height shares a single window.
-TE_HD bool rotate_piece_band(const Ctx& cx, Player& q, int turn, uint64_t& b0) {
-    int nr = (q.rot + turn) & 3;
-    uint32_t shape = shape_of(cx, q.kind, nr);
+// rotations and sideways moves at one height shares a single window.  `b1` caches band_window(q.y + 1)
+// (valid while b1_ok).
+TE_HD bool rotate_shape_band(const Ctx& cx, Player& q, int nr, uint32_t shape, uint64_t& b0, uint64_t& b1, bool& b1_ok) {
     if (fits_band(b0, shape, q.x)) { q.rot = nr; return true; }
-    uint64_t b1 = band_window(cx, q, q.y + 1);
+    if (!b1_ok) { b1 = band_window(cx, q, q.y + 1); b1_ok = true; }
     // (dx,dy) in the reference's order: (0,+1) (-1,0) (+1,0) (-1,+1) (+1,+1) (-2,0) (+2,0)
     int dx = 99, dy = 0;
     if (fits_band(b1, shape, q.x)) { dx = 0; dy = 1; }
@@ -622,8 +606,15 @@ TE_HD bool rotate_piece_band(const Ctx& cx, Player& q, int turn, uint64_t& b0) {
     else if (fits_band(b0, shape, q.x + 2)) { dx = 2; }
     if (dx == 99) return false;
     q.rot = nr; q.x += dx; q.y += dy;
-    if (dy) b0 = b1;
+    if (dy) { b0 = b1; b1_ok = false; }
     return true;
+}
+
+TE_HD bool rotate_piece_band(const Ctx& cx, Player& q, int turn, uint64_t& b0) {
+    uint64_t b1 = 0;
+    bool b1_ok = false;
+    const int nr = (q.rot + turn) & 3;
+    return rotate_shape_band(cx, q, nr, shape_of(cx, q.kind, nr), b0, b1, b1_ok);
 }
 
 TE_HD bool rotate_piece(const Ctx& cx, Player& q, int turn) {
@@ -700,8 +691,13 @@ TE_HD void play_rt(const Ctx& cx, Player& q, int r, int t) {
     if (easy) {
         q.rot = (q.rot + r) & 3;
     } else {
+        uint64_t b1 = 0;
+        bool b1_ok = false;
         for (int i = 0; i < 3; i++)
-            if (i < r) rotate_piece_band(cx, q, 1, band);
+            if (i < r) {
+                const int nr = (q.rot + 1) & 3;
+                rotate_shape_band(cx, q, nr, pick4(sh, nr), band, b1, b1_ok);
+            }
     }
     const uint32_t shape = pick4(sh, q.rot);
     const uint32_t free = free_positions(band, shape);

@@ -62,13 +62,13 @@ __global__ __launch_bounds__(256) void k_gen_seed(uint32_t* mt) {
 
 struct MapArg { uint8_t m[8]; };
 
-__global__ __launch_bounds__(256) void k_gen_chunk(uint32_t* mt, float* w, uint8_t* out, uint8_t* first_ok, int chunk,
+__global__ __launch_bounds__(256) void k_gen_chunk(uint32_t* mt, float* w, uint8_t* out, uint32_t* start, int chunk,
                                                    MapArg map, int only_sz) {
     uint32_t seed = blockIdx.x * blockDim.x + threadIdx.x;
     if (seed >= 65536u) return;
-    uint8_t fo = 0;
-    gen_chunk_for_seed(mt + seed, 65536, w + seed, 65536, out + (size_t)seed * CHUNK, &fo, chunk, map.m, only_sz != 0);
-    if (chunk == 0) first_ok[seed] = fo;
+    uint32_t word = 0;
+    gen_chunk_for_seed(mt + seed, 65536, w + seed, 65536, out + (size_t)seed * CHUNK, &word, chunk, map.m, only_sz != 0);
+    if (chunk == 0) start[seed] = word;
 }
 
 template <int P>
@@ -167,7 +167,7 @@ struct Tables {
     int refs = 0;
     uint32_t* d_mt = nullptr;        // [624][65536]
     float* d_w = nullptr;            // [7][65536]
-    uint8_t* d_first_ok = nullptr;   // [65536]
+    uint32_t* d_start = nullptr;     // [65536] per-seed start words
     double* d_pow = nullptr;         // [256]
     uint8_t* d_table = nullptr;      // [(chunk * 65536 + seed) * 624 + r], capacity `cap_chunks`
     int n_chunks = 0, cap_chunks = 0;
@@ -192,7 +192,7 @@ static int tables_extend(Tables* t, hipStream_t stream) {
     MapArg m;
     memcpy(m.m, t->map, 8);
     hipLaunchKernelGGL(k_gen_chunk, dim3(256), dim3(256), 0, stream, t->d_mt, t->d_w, t->d_table + CHUNK_BYTES * t->n_chunks,
-                       t->d_first_ok, t->n_chunks, m, t->only_sz);
+                       t->d_start, t->n_chunks, m, t->only_sz);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(stream));
     t->n_chunks++;
@@ -211,7 +211,7 @@ static int tables_acquire(Tables** out, int device, const uint8_t map[7], hipStr
     for (int i = 0; i < 7; i++) if (map[i] != 2 && map[i] != 3) t->only_sz = 0;
     HIP_TRY(hipMalloc((void**)&t->d_mt, (size_t)624 * 65536 * 4));
     HIP_TRY(hipMalloc((void**)&t->d_w, (size_t)7 * 65536 * 4));
-    HIP_TRY(hipMalloc((void**)&t->d_first_ok, 65536));
+    HIP_TRY(hipMalloc((void**)&t->d_start, 65536 * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void**)&t->d_pow, 256 * sizeof(double)));
     double powtab[256];
     for (int c = 0; c < 256; c++) powtab[c] = pow((double)c, 1.4 + (double)c * 0.01);   // Combo.cpp:41, host libm
@@ -234,7 +234,7 @@ static void tables_release(Tables* t) {
     if (--t->refs > 0) return;
     for (size_t i = 0; i < g_tables.size(); i++)
         if (g_tables[i] == t) { g_tables.erase(g_tables.begin() + i); break; }
-    (void)hipFree(t->d_mt); (void)hipFree(t->d_w); (void)hipFree(t->d_first_ok); (void)hipFree(t->d_pow);
+    (void)hipFree(t->d_mt); (void)hipFree(t->d_w); (void)hipFree(t->d_start); (void)hipFree(t->d_pow);
     (void)hipFree(t->d_table);
     for (uint8_t* c : t->retired) (void)hipFree(c);
     delete t;
@@ -282,7 +282,7 @@ static KArgs base_args(tetris_batch* b, int n, const int32_t* d_idx) {
     KArgs a;
     memset(&a, 0, sizeof a);
     a.state = b->d_state; a.gstate = b->d_gstate; a.status = b->d_status;
-    a.table = b->tab->d_table; a.first_ok = b->tab->d_first_ok; a.combo_pow = b->tab->d_pow;
+    a.table = b->tab->d_table; a.start = b->tab->d_start; a.combo_pow = b->tab->d_pow;
     a.n_draws = (uint32_t)b->tab->n_chunks * CHUNK; a.margin = b->margin;
     a.H = b->H; a.n_games = b->N; a.n = n; a.idx = d_idx; a.game_offset = b->game_offset;
     return a;

@@ -15,7 +15,7 @@ struct KArgs {
     uint32_t* gstate;
     uint32_t* status;
     const uint8_t* table;     // [(chunk * 65536 + seed16) * 624 + r]
-    const uint8_t* first_ok;
+    const uint32_t* start;    // [65536] per-seed start words
     const double* combo_pow;
     uint32_t n_draws, margin;
     int H;
@@ -48,7 +48,7 @@ TE_HD Ctx make_ctx(const KArgs& a, const uint32_t* shapes) {
     Ctx cx;
     cx.shapes = shapes;
     cx.table = a.table;
-    cx.first_ok = a.first_ok;
+    cx.start = a.start;
     cx.combo_pow = a.combo_pow;
     cx.n_draws = a.n_draws;
     cx.margin = a.margin;
@@ -132,7 +132,7 @@ TE_HD void game_run(const KArgs& a, int i, const uint32_t* shapes, Game<P>& g, L
             TE_UNROLL
             for (int p = 0; p < P; p++) prefetch_next(cx, g.pl[p], g.seed16, g.status);
             ResetPrefetch rpf;
-            prefetch_reset<P>(cx, g, episode_seed(a.game_offset + (uint32_t)slot, g.episode + 1), rpf);
+            prefetch_reset(cx, episode_seed(a.game_offset + (uint32_t)slot, g.episode + 1), rpf);
             uint32_t w[4];
 #if defined(TE_ABLATE) && (TE_ABLATE & 1)
             w[0] = (uint32_t)slot + (uint32_t)step; w[1] = (uint32_t)slot * 7u + (uint32_t)step;   // diagnostic build: no Philox

@@ -10,8 +10,9 @@
 //    randomizer.cpp:10-32,55-62) => the *sequence of dealt pieces* is a pure function of the seed
 //    (and of the batch-wide piece map, PythonHandle.h:116-121).
 //  => table[seed][k] = piece dealt by draw k (low nibble) | hole chosen by draw k (high nibble),
-//     first_ok[seed] = index j of the first draw accepted by the S/Z redraw loop.  After a reset a
-//     board holds current = piece(j), next = piece(j+1), piece_draws = j+2, hole_draws = 0.
+//     start[seed] = j | table(j) << 8 | table(j+1) << 16 with j = index of the first draw accepted by the
+//     S/Z redraw loop.  After a reset a board holds current = piece(j), next = piece(j+1),
+//     piece_draws = j+2, hole_draws = 0 — one 4-byte load.
 //
 // std::mt19937 itself is libstdc++ (third party, not vendored in the reference): the published
 // MT19937 (Matsumoto & Nishimura 1998), init_genrand seeding; KAT in tests (seed 1000 ->
@@ -99,7 +100,9 @@ TE_HD int pick_hole(uint32_t draw) { return (int)(short)(unit_float(draw) * 10.0
 //   out     : 624 bytes of this seed's row in the chunk table
 //   first_ok: written when chunk == 0
 TE_HD void gen_chunk_for_seed(uint32_t* mt, size_t stride, float* w, size_t ws, uint8_t* out,
-                              uint8_t* first_ok, int chunk, const uint8_t* map, bool only_sz) {
+                              uint32_t* start_word, int chunk, const uint8_t* map, bool only_sz) {
+    uint8_t first_ok_store = 0;
+    uint8_t* first_ok = &first_ok_store;
     mt_twist(mt, stride);
     bool redraw_open = (chunk == 0);       // gamePlay.cpp:218-230: weights reset before every draw
     if (chunk == 0) *first_ok = 0;         // up to and including the first one that is not S/Z
@@ -116,6 +119,12 @@ TE_HD void gen_chunk_for_seed(uint32_t* mt, size_t stride, float* w, size_t ws, 
         uint32_t byte = (uint32_t)piece | ((uint32_t)pick_hole(u) << 4);
         packed |= byte << (8 * (k & 3));
         if ((k & 3) == 3) { ((uint32_t*)out)[k >> 2] = packed; packed = 0; }
+    }
+    // start word of this seed: everything a reset reads, in one 4-byte load:
+    //   first_ok j [0:8) | table byte of draw j [8:16) | table byte of draw j+1 [16:24)
+    if (chunk == 0) {
+        uint32_t j = first_ok_store;
+        *start_word = j | ((uint32_t)out[j] << 8) | ((uint32_t)out[j + 1] << 16);
     }
 }
 

@@ -26,7 +26,7 @@ struct Tables {
     int only_sz = 0;
     std::vector<uint32_t> mt;        // [624][65536]
     std::vector<float> w;            // [7][65536]
-    std::vector<uint8_t> first_ok;   // [65536]
+    std::vector<uint32_t> start;     // [65536] per-seed start words
     double powtab[256];
     std::vector<uint8_t> table;      // [(chunk * 65536 + seed) * 624 + r]
     int n_chunks = 0;
@@ -36,9 +36,9 @@ struct Tables {
         uint8_t* out = table.data() + (size_t)65536 * CHUNK * c;
 #pragma omp parallel for schedule(static)
         for (int seed = 0; seed < 65536; seed++) {
-            uint8_t fo = 0;
-            gen_chunk_for_seed(mt.data() + seed, 65536, w.data() + seed, 65536, out + (size_t)seed * CHUNK, &fo, c, map, only_sz != 0);
-            if (c == 0) first_ok[seed] = fo;
+            uint32_t word = 0;
+            gen_chunk_for_seed(mt.data() + seed, 65536, w.data() + seed, 65536, out + (size_t)seed * CHUNK, &word, c, map, only_sz != 0);
+            if (c == 0) start[seed] = word;
         }
         n_chunks++;
     }
@@ -55,7 +55,7 @@ static Tables* tables_for(const uint8_t map[7]) {
     for (int i = 0; i < 7; i++) if (map[i] != 2 && map[i] != 3) t->only_sz = 0;
     t->mt.resize((size_t)624 * 65536);
     t->w.resize((size_t)7 * 65536);
-    t->first_ok.resize(65536);
+    t->start.resize(65536);
     for (int c = 0; c < 256; c++) t->powtab[c] = pow((double)c, 1.4 + (double)c * 0.01);
 #pragma omp parallel for schedule(static)
     for (int seed = 0; seed < 65536; seed++) mt_seed(t->mt.data() + seed, 65536, (uint32_t)(int32_t)(int16_t)(uint16_t)seed);
@@ -78,7 +78,7 @@ static KArgs base_args(tetris_batch* b, int n, const int32_t* idx) {
     KArgs a;
     memset(&a, 0, sizeof a);
     a.state = b->state.data(); a.gstate = b->gstate.data(); a.status = &b->status;
-    a.table = b->tab->table.data(); a.first_ok = b->tab->first_ok.data(); a.combo_pow = b->tab->powtab;
+    a.table = b->tab->table.data(); a.start = b->tab->start.data(); a.combo_pow = b->tab->powtab;
     a.n_draws = (uint32_t)b->tab->n_chunks * CHUNK; a.margin = b->margin;
     a.H = b->H; a.n_games = b->N; a.n = n; a.idx = idx; a.game_offset = b->game_offset;
     return a;
