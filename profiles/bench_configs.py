@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Secondary measurements for the BASELINE.json configs that are not bench.py's headline line:
+C3 (64k two-player boards), C4 (drop-afterstate enumeration on 16k boards), the observation kernel and
+get_actions.  Device-side times from HIP events around repeated launches; prints one JSON object."""
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+import __graft_entry__ as ge
+
+pkg = ge.package()
+out = {}
+
+
+def advance(b, steps):
+    b.rollout_random(steps, 1)
+
+
+# C2 / C3: rollout, one env-step per launch
+for P in (1, 2):
+    b = pkg.TetrisBatch(65536, P, 20, 10, seeds=np.arange(65536))
+    advance(b, 64)
+    c, ms = b.rollout_random(2048, 1, first_step=64)
+    out[f"C{1 + P}_rollout_{P}p_64k"] = {"env_steps_per_s": 65536 * 2048 / (ms * 1e-3), "us_per_launch": ms * 1e3 / 2048,
+                                        "player_board_steps_per_s": P * 65536 * 2048 / (ms * 1e-3)}
+    b.close()
+
+# C4: enumerate_drops on 16 384 boards taken at step 12 of each episode
+b = pkg.TetrisBatch(16384, 1, 20, 10, seeds=np.arange(16384))
+advance(b, 12)
+valid, land, cleared, after = b.enumerate_drops()
+t0 = time.perf_counter()
+reps = 20
+for _ in range(reps):
+    b.enumerate_drops(columns=True)
+host_s = (time.perf_counter() - t0) / reps
+out["C4_enumerate_drops_16k"] = {"afterstates_per_call": int(16384 * 40), "valid_fraction": float(valid.mean()),
+                                 "host_call_s_incl_pcie": host_s, "afterstates_per_s_incl_pcie": 16384 * 40 / host_s}
+b.close()
+
+# observation kernel + get_actions, host-inclusive (PCIe + numpy) timings
+b = pkg.TetrisBatch(65536, 2, 20, 10, seeds=np.arange(65536))
+advance(b, 12)
+t0 = time.perf_counter()
+for _ in range(5):
+    b.observe_packed(player=0)
+out["observe_packed_64k_2p"] = {"host_call_s_incl_pcie": (time.perf_counter() - t0) / 5, "bytes_out": 2 * 65536 * (200 + 12 + 1)}
+sub = np.arange(4096, dtype=np.int32)
+t0 = time.perf_counter()
+lists = b.get_actions(sub, player=0)
+dt = time.perf_counter() - t0
+out["get_actions_4096_boards"] = {"host_call_s_incl_pcie_and_python_lists": dt, "mean_lists_per_board": float(np.mean([len(l) for l in lists])),
+                                  "max_lists": int(max(len(l) for l in lists)), "max_keys": int(max(len(a) for l in lists for a in l))}
+b.close()
+print(json.dumps(out))
