@@ -66,6 +66,9 @@ _SIGNATURES = {
     "tetris_get_actions": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "tetris_observe_packed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "tetris_observe_packed_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "tetris_create_split": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "tetris_split_stage_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "tetris_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "tetris_rollout_random": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_uint32, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p]),
     "tetris_device_state": (C.c_void_p, [C.c_void_p]),
     "tetris_stream": (C.c_void_p, [C.c_void_p]),
@@ -105,14 +108,23 @@ def _u8(a, shape=None):
 class TetrisBatch:
     """N games resident on one GPU (one `tetris_batch`)."""
 
-    def __init__(self, n_games, n_players=2, height=20, width=10, pieces=(0, 1, 2, 3, 4, 5, 6), seeds=None, device=0, lib_path=None):
+    def __init__(self, n_games, n_players=2, height=20, width=10, pieces=(0, 1, 2, 3, 4, 5, 6), seeds=None, device=0, lib_path=None,
+                 split_side=None):
+        """split_side = 0 / 1: this batch holds only that player of n_games two-player games (opponents on another GPU)."""
         self.lib = load_library(lib_path)
+        self.split_side = split_side
+        if split_side is not None:
+            n_players = 1
         self.n_games, self.n_players, self.height, self.width = int(n_games), int(n_players), int(height), int(width)
         self.piece_map = np.array((list(pieces) * 7)[:7], dtype=np.uint8)      # tetris_environment.py:191-193
         self._h = C.c_void_p()
         s = self._seeds(seeds, self.n_games) if seeds is not None else None
-        self._check(self.lib.tetris_create(C.byref(self._h), self.n_games, self.n_players, self.height, self.width,
-                                           _p(self.piece_map), int(device), _p(s)))
+        if split_side is None:
+            self._check(self.lib.tetris_create(C.byref(self._h), self.n_games, self.n_players, self.height, self.width,
+                                               _p(self.piece_map), int(device), _p(s)))
+        else:
+            self._check(self.lib.tetris_create_split(C.byref(self._h), self.n_games, int(split_side), self.height, self.width,
+                                                     _p(self.piece_map), int(device), _p(s)))
         self.snapshot_words = self.lib.tetris_snapshot_words(self._h)
 
     # -- plumbing
@@ -253,6 +265,13 @@ class TetrisBatch:
         self._check(self.lib.tetris_rollout_random(self._h, int(launches), int(steps_per_launch), int(policy_seed), int(first_step),
                                                    int(ms), _p(counters), C.byref(elapsed)))
         return counters, float(elapsed.value)
+
+    def split_stage(self, stage, rot=None, trans=None, acting=None, words=None, out=None, done=None, lines=None, dead=None, ms=400):
+        """One stage of a split-mode step; every argument is a raw device address (int) or None."""
+        self._check(self.lib.tetris_split_stage_dev(self._h, int(stage), rot, trans, acting, int(ms), words, out, done, lines, dead))
+
+    def set_stream(self, stream_ptr):
+        self._check(self.lib.tetris_set_stream(self._h, stream_ptr))
 
     def set_game_offset(self, first_game_id):
         self._check(self.lib.tetris_set_game_offset(self._h, int(first_game_id)))

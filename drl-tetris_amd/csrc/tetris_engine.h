@@ -126,6 +126,7 @@ struct Game {
     Player pl[P];
     uint32_t seed16;                 // low 16 bits of the seed (table row)
     int round_over, last_winner;
+    uint32_t flags;                  // split mode (cross-device opponents): side[0] opp_dead[1] split[2]
     uint32_t episode;
     uint32_t roll_lines, roll_sent;  // cumulative rollout counters (G_LINES, G_SENT)
     uint32_t status;                 // te::Status bits raised while stepping this game
@@ -139,6 +140,7 @@ TE_HD void load_game(const uint32_t* state, const uint32_t* gstate, size_t n, si
     g.seed16 = meta & 0xFFFFu;
     g.round_over = (meta >> 16) & 1;
     g.last_winner = (int)((meta >> 17) & 0xF) - 1;
+    g.flags = (meta >> 21) & 7u;
     g.episode = ld_stream(&gstate[(size_t)G_EPISODE * n + slot]);
     g.roll_lines = ld_stream(&gstate[(size_t)G_LINES * n + slot]);
     g.roll_sent = ld_stream(&gstate[(size_t)G_SENT * n + slot]);
@@ -186,7 +188,7 @@ TE_HD void load_game(const uint32_t* state, const uint32_t* gstate, size_t n, si
 
 template <int P>
 TE_HD void store_game(uint32_t* state, uint32_t* gstate, size_t n, size_t slot, const Game<P>& g) {
-    st_stream(&gstate[(size_t)G_META * n + slot], g.seed16 | ((uint32_t)g.round_over << 16) | ((uint32_t)(g.last_winner + 1) << 17));
+    st_stream(&gstate[(size_t)G_META * n + slot], g.seed16 | ((uint32_t)g.round_over << 16) | ((uint32_t)(g.last_winner + 1) << 17) | (g.flags << 21));
     st_stream(&gstate[(size_t)G_EPISODE * n + slot], g.episode);
     st_stream(&gstate[(size_t)G_LINES * n + slot], g.roll_lines);
     st_stream(&gstate[(size_t)G_SENT * n + slot], g.roll_sent);
@@ -581,7 +583,7 @@ TE_HD void init_game(const Ctx& cx, Game<P>& g, uint32_t seed16) {
         q.reward = 0; q.inc_count = 0; q.combo_remaining = 0; q.dead = 0; q.next = 0; q.kind = 7; q.rot = 0;
         q.q_loaded = 1;
     }
-    g.episode = 0; g.roll_lines = 0; g.roll_sent = 0; g.status = 0;
+    g.episode = 0; g.roll_lines = 0; g.roll_sent = 0; g.status = 0; g.flags = 0;
     reset_game(cx, g, seed16);
     g.last_winner = -1;
 }
@@ -985,6 +987,73 @@ TE_HD int finish_game(const Ctx& cx, Game<P>& g, int ms) {
     }
     if ((P > 1 && alive < 2) || !alive) { g.round_over = 1; return 1; }
     return 0;
+}
+
+// ---------------------------------------------------------------- split mode: opponents on different GPUs
+// One batch holds ONE side (player index `side`) of N two-player games; the other side lives in another batch,
+// normally on another GPU.  The only cross-board traffic of the engine is PythonHandle::distributeLines
+// (PythonHandle.cpp:124-136) plus the dead flags of the winner logic, so a step is cut into three stages with an
+// exchange of one 32-bit word per board after each (an RCCL all-gather in drl-tetris_amd/distributed.py):
+//   A  key interpreter + loop 1 of finish_actions (clear, send/block, new piece; PythonHandle.cpp:151-158).
+//      Player 1 runs it SPECULATIVELY: the reference skips player 1 when player 0 died in loop 1 (`break`), which
+//      side 1 only learns from the exchange, so it keeps both its pre- and post-settle state.
+//   B  loop 2 (delayCheck), player 0 first, then (after a second exchange) player 1 — player 0's combo lines reach
+//      player 1's garbage queue in the same step (PythonHandle.cpp:160-180).
+//   C  after the third exchange: player 1's tick lines reach player 0, winner / round_over (:182-187).
+// Exchange word: sent[0:16) | DIED[16] | DEAD_NOW[17] | RAN[18].
+constexpr uint32_t XW_DIED = 1u << 16, XW_DEAD_NOW = 1u << 17, XW_RAN = 1u << 18;
+constexpr uint32_t SPLIT_SIDE = 1u, SPLIT_OPP_DEAD = 2u, SPLIT_ON = 4u;
+TE_HD int xw_sent(uint32_t w) { return (int)(w & 0xFFFFu); }
+
+// stage A after the key interpreter: loop-1 body for my player.  Returns my exchange word.
+TE_HD uint32_t split_settle(const Ctx& cx, Game<1>& g) {
+    Player& q = g.pl[0];
+    if (g.round_over || q.dead) return 0u;
+    int sent = settle(cx, q, g.seed16, g.status);
+    if (sent == -1) { q.dead = 1; return XW_RAN | XW_DIED; }
+    return XW_RAN | (uint32_t)(sent & 0xFFFF);
+}
+
+// stage B: my player's delayCheck.  `first_in` = lines that reach me before my tick.  Returns my word.
+TE_HD uint32_t split_tick(const Ctx& cx, Game<1>& g, int ms, int lines_in) {
+    Player& q = g.pl[0];
+    if (g.round_over) return q.dead ? XW_DEAD_NOW : 0u;
+    if (lines_in > 0) q.incoming = q.incoming + (float)lines_in / 1.0f;       // amount / (P - 1), P = 2
+    uint32_t w = 0;
+    if (!q.dead) {
+        int sent = tick(cx, q, ms, g.seed16, g.status);
+        if (sent == -1) { q.dead = 1; w = XW_DIED; }
+        else {
+            w = (uint32_t)(sent & 0xFFFF);
+            q.reward = (int)((q.lines_cleared - q.lines_seen) & 0xFFu);
+            q.lines_seen = q.lines_cleared;
+            q.inc_count = q_total(q) & 255;
+        }
+    }
+    return w | (q.dead ? XW_DEAD_NOW : 0u);
+}
+
+// stage C: lines that arrive after my tick, then PythonHandle.cpp:182-187 with the opponent's final dead flag
+TE_HD int split_finish(Game<1>& g, int lines_in, bool opp_dead) {
+    Player& q = g.pl[0];
+    if (g.round_over) return 1;
+    if (lines_in > 0) q.incoming = q.incoming + (float)lines_in / 1.0f;
+    g.flags = (g.flags & ~SPLIT_OPP_DEAD) | (opp_dead ? SPLIT_OPP_DEAD : 0u);
+    int alive = (q.dead ? 0 : 1) + (opp_dead ? 0 : 1);
+    if (alive < 2) { g.round_over = 1; return 1; }
+    return 0;
+}
+
+// PythonHandle.cpp:49-71 reset for one side of a split game: last_winner needs both dead flags
+TE_HD void reset_split(const Ctx& cx, Game<1>& g, uint32_t seed16) {
+    const int side = (int)(g.flags & SPLIT_SIDE);
+    const bool me_alive = !g.pl[0].dead, opp_alive = !(g.flags & SPLIT_OPP_DEAD);
+    int winner = -1;
+    if (me_alive && !opp_alive) winner = side;
+    if (opp_alive && !me_alive) winner = 1 - side;
+    reset_game<1>(cx, g, seed16);
+    g.last_winner = winner;                        // both alive: -1 (alive_count > 1); none alive: -1
+    g.flags &= ~SPLIT_OPP_DEAD;
 }
 
 // seed16 = (12345 + 7919 i + 104729 e) mod 65536

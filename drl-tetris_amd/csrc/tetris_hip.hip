@@ -52,6 +52,15 @@ __global__ __launch_bounds__(256) void k_totals(const uint32_t* gstate, int n_ga
     }
 }
 
+template <int STAGE>
+__global__ __launch_bounds__(256) void k_split(KArgs a) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_shapes[32];
+    if (threadIdx.x < 32) s_shapes[threadIdx.x] = d_shape_table.s[threadIdx.x];
+    __syncthreads();
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < a.n) split_body<STAGE>(a, i, s_shapes);
+}
+
 // ---- RNG tables: one lane per 16-bit seed, MT state strided [word][seed] (coalesced)
 __global__ __launch_bounds__(256) void k_gen_seed(uint32_t* mt) {
     uint32_t seed = blockIdx.x * blockDim.x + threadIdx.x;
@@ -275,6 +284,9 @@ struct tetris_batch {
     Tables* tab = nullptr;
     uint32_t margin = 64;
     uint32_t game_offset = 0;
+    int split = 0, side = 0;
+    uint32_t* d_shadow = nullptr;        // split mode, side 1
+    hipStream_t own_stream = nullptr;
     Stage s_idx, s_in0, s_in1, s_in2, s_out0, s_out1, s_out2, s_big;
 };
 
@@ -371,19 +383,19 @@ int tetris_destroy(tetris_batch* b) {
     (void)hipSetDevice(b->device);
     if (b->stream) (void)hipStreamSynchronize(b->stream);
     if (b->tab) tables_release(b->tab);
-    (void)hipFree(b->d_state); (void)hipFree(b->d_gstate); (void)hipFree(b->d_status); (void)hipFree(b->d_counters);
+    (void)hipFree(b->d_shadow); (void)hipFree(b->d_state); (void)hipFree(b->d_gstate); (void)hipFree(b->d_status); (void)hipFree(b->d_counters);
     if (b->h_status) (void)hipHostFree(b->h_status);
     Stage* all[] = {&b->s_idx, &b->s_in0, &b->s_in1, &b->s_in2, &b->s_out0, &b->s_out1, &b->s_out2, &b->s_big};
     for (Stage* s : all) s->release();
     if (b->ev0) (void)hipEventDestroy(b->ev0);
     if (b->ev1) (void)hipEventDestroy(b->ev1);
-    if (b->stream) (void)hipStreamDestroy(b->stream);
+    if (b->own_stream) (void)hipStreamDestroy(b->own_stream);
     delete b;
     return TETRIS_OK;
 }
 
-int tetris_create(tetris_batch** out, int n_games, int n_players, int height, int width, const uint8_t piece_map[7],
-                  int device, const int16_t* seeds) {
+static int create_impl(tetris_batch** out, int n_games, int n_players, int height, int width, const uint8_t piece_map[7],
+                       int device, const int16_t* seeds, int split, int side) {
     if (!out) return fail(TETRIS_E_ARG, "out is NULL");
     *out = nullptr;
     if (n_games < 1) return fail(TETRIS_E_ARG, "n_games must be >= 1");
@@ -412,6 +424,7 @@ int tetris_create(tetris_batch** out, int n_games, int n_players, int height, in
         }                                                                                   \
     } while (0)
     CREATE_TRY(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+    b->own_stream = b->stream;
     CREATE_TRY(hipEventCreate(&b->ev0));
     CREATE_TRY(hipEventCreate(&b->ev1));
     CREATE_TRY(hipMalloc((void**)&b->d_state, (size_t)NWORDS * n_players * n_games * 4));
@@ -430,9 +443,12 @@ int tetris_create(tetris_batch** out, int n_games, int n_players, int height, in
         if (rc) { std::string keep = g_err; tetris_destroy(b); return fail(rc, keep); }
         d_seeds = (const int16_t*)b->s_in0.d;
     }
+    b->split = split; b->side = side;
+    if (split && side == 1) CREATE_TRY(hipMalloc((void**)&b->d_shadow, (size_t)NWORDS * n_players * n_games * 4));
     KArgs a = base_args(b, n_games, nullptr);
     a.seeds = d_seeds;
-    rc = launch_game<M_INIT>(b, a);
+    a.steps = side;
+    rc = split ? launch_game<M_SPLIT_INIT>(b, a) : launch_game<M_INIT>(b, a);
     if (!rc) rc = finish_call(b);
     if (rc) { std::string keep = g_err; tetris_destroy(b); return fail(rc, keep); }
     *out = b;
@@ -442,6 +458,45 @@ int tetris_create(tetris_batch** out, int n_games, int n_players, int height, in
 int tetris_set_game_offset(tetris_batch* b, uint64_t first_game_id) {
     if (!b) return fail(TETRIS_E_ARG, "null batch");
     b->game_offset = (uint32_t)first_game_id;
+    return TETRIS_OK;
+}
+
+int tetris_create(tetris_batch** out, int n_games, int n_players, int height, int width, const uint8_t piece_map[7],
+                  int device, const int16_t* seeds) {
+    return create_impl(out, n_games, n_players, height, width, piece_map, device, seeds, 0, 0);
+}
+
+int tetris_create_split(tetris_batch** out, int n_games, int side, int height, int width, const uint8_t piece_map[7], int device,
+                        const int16_t* seeds) {
+    if (side != 0 && side != 1) return fail(TETRIS_E_ARG, "side must be 0 or 1");
+    return create_impl(out, n_games, 1, height, width, piece_map, device, seeds, 1, side);
+}
+
+int tetris_set_stream(tetris_batch* b, void* hip_stream) {
+    int rc = check_batch(b);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    b->stream = hip_stream ? (hipStream_t)hip_stream : b->own_stream;
+    return TETRIS_OK;
+}
+
+int tetris_split_stage_dev(tetris_batch* b, int stage, const uint8_t* d_rot, const uint8_t* d_trans, const uint8_t* d_acting, int ms,
+                           const uint32_t* d_words, uint32_t* d_out, uint8_t* d_done, uint8_t* d_lines, uint8_t* d_dead) {
+    int rc = check_batch(b);
+    if (rc) return rc;
+    if (!b->split) return fail(TETRIS_E_ARG, "not a split batch (tetris_create_split)");
+    if (stage < 0 || stage > 2) return fail(TETRIS_E_ARG, "stage must be 0, 1 or 2");
+    if (stage == 0 && (!d_rot || !d_trans)) return fail(TETRIS_E_ARG, "stage 0 needs rot/trans");
+    if (stage < 2 && !d_out) return fail(TETRIS_E_ARG, "stages 0 and 1 need d_out");
+    if (stage > 0 && !d_words) return fail(TETRIS_E_ARG, "stages 1 and 2 need d_words");
+    KArgs a = base_args(b, b->N, nullptr);
+    a.rot = d_rot; a.trans = d_trans; a.player = d_acting; a.ms = ms;
+    a.shadow = b->d_shadow; a.xw = d_words; a.xout = d_out; a.done = d_done; a.lines = d_lines; a.dead = d_dead;
+    dim3 grid((unsigned)((b->N + 255) / 256)), block(256);
+    if (stage == 0) hipLaunchKernelGGL(k_split<0>, grid, block, 0, b->stream, a);
+    else if (stage == 1) hipLaunchKernelGGL(k_split<1>, grid, block, 0, b->stream, a);
+    else hipLaunchKernelGGL(k_split<2>, grid, block, 0, b->stream, a);
+    HIP_TRY(hipGetLastError());
     return TETRIS_OK;
 }
 
@@ -462,7 +517,7 @@ int tetris_reset(tetris_batch* b, const int32_t* idx, int n, const int16_t* seed
         if ((rc = stage_in(b, b->s_in0, seeds, (size_t)n * 2))) return rc;
         a.seeds = (const int16_t*)b->s_in0.d;
     }
-    if ((rc = launch_game<M_RESET>(b, a))) return rc;
+    if ((rc = b->split ? launch_game<M_SPLIT_RESET>(b, a) : launch_game<M_RESET>(b, a))) return rc;
     return finish_call(b);
 }
 

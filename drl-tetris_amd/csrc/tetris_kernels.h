@@ -38,9 +38,12 @@ struct KArgs {
     unsigned long long first_step;
     unsigned long long* counters;
     uint32_t game_offset;     // global id of slot 0 (rollout policy / seed schedule)
+    uint32_t* shadow;         // split mode, side 1: post-settle state of the speculative loop-1 pass
+    const uint32_t* xw;       // split mode: exchange words [4][n]: my A, opponent's A, player 0's B, player 1's B
+    uint32_t* xout;           // split mode: this stage's word per board [n]
 };
 
-enum Mode { M_INIT, M_RESET, M_MAKE, M_FINISH, M_STEP_KEYS, M_STEP_RT, M_ROLLOUT };
+enum Mode { M_INIT, M_RESET, M_MAKE, M_FINISH, M_STEP_KEYS, M_STEP_RT, M_ROLLOUT, M_SPLIT_INIT, M_SPLIT_RESET };
 
 struct LaneCounters { unsigned long long steps, episodes, lines, sent; };   // used by the CPU test harness only
 
@@ -94,7 +97,7 @@ TE_HD void make_rt(const Ctx& cx, Game<P>& g, int player, int r, int t) {
 template <int P, int MODE>
 TE_HD void game_load(const KArgs& a, int i, Game<P>& g) {
     const size_t slot = a.idx ? (size_t)a.idx[i] : (size_t)i;
-    if (MODE != M_INIT) load_game<P>(a.state, a.gstate, (size_t)a.n_games, slot, g);
+    if (MODE != M_INIT && MODE != M_SPLIT_INIT) load_game<P>(a.state, a.gstate, (size_t)a.n_games, slot, g);
 }
 
 // Phase 2: step and store.
@@ -104,7 +107,12 @@ TE_HD void game_run(const KArgs& a, int i, const uint32_t* shapes, Game<P>& g, L
     const size_t slot = a.idx ? (size_t)a.idx[i] : (size_t)i;
     Ctx cx = make_ctx(a, shapes);
     if (MODE == M_INIT) init_game<P>(cx, g, (uint32_t)(a.seeds ? (uint16_t)a.seeds[i] : 0));
-    if (MODE == M_RESET) {
+    if (MODE == M_SPLIT_INIT) {           // a.steps carries the side this batch holds
+        init_game<P>(cx, g, (uint32_t)(a.seeds ? (uint16_t)a.seeds[i] : 0));
+        g.flags = SPLIT_ON | (a.steps ? SPLIT_SIDE : 0u);
+    } else if (MODE == M_SPLIT_RESET) {
+        if (P == 1) reset_split(cx, *reinterpret_cast<Game<1>*>(&g), (uint32_t)(a.seeds ? (uint16_t)a.seeds[i] : 0));
+    } else if (MODE == M_RESET) {
         reset_game<P>(cx, g, (uint32_t)(a.seeds ? (uint16_t)a.seeds[i] : 0));
     } else if (MODE == M_MAKE) {
         make_keys<P>(cx, a, i, g);
@@ -166,6 +174,60 @@ TE_HD void game_run(const KArgs& a, int i, const uint32_t* shapes, Game<P>& g, L
         }
     }
     store_game<P>(a.state, a.gstate, N, slot, g);
+    if (g.status) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        atomicOr(a.status, g.status);
+#else
+        *a.status |= g.status;
+#endif
+    }
+}
+
+// Split mode (opponents on different GPUs, tetris_engine.h): one stage of a step for the side this batch holds.
+template <int STAGE>
+TE_HD void split_body(const KArgs& a, int i, const uint32_t* shapes) {
+    const size_t N = (size_t)a.n_games;
+    Ctx cx = make_ctx(a, shapes);
+    Game<1> g;
+    const uint32_t my_a = STAGE > 0 ? a.xw[i] : 0u;
+    const uint32_t opp_a = STAGE > 0 ? a.xw[(size_t)a.n + i] : 0u;
+    // side 1 continues from its speculative post-settle state unless player 0 died in loop 1
+    const uint32_t meta = a.gstate[(size_t)G_META * N + i];
+    const int side = (int)((meta >> 21) & 1u);
+    const bool from_shadow = STAGE == 1 && side == 1 && !(opp_a & XW_DIED);
+    load_game<1>(from_shadow ? a.shadow : a.state, a.gstate, N, (size_t)i, g);
+    Player& q = g.pl[0];
+    if (STAGE == 0) {
+        const int acting = a.player ? a.player[i] : 0;
+        prefetch_next(cx, q, g.seed16, g.status);
+        if (!g.round_over && !q.dead && acting == side) play_rt(cx, q, a.rot[i] & 3, a.trans[i]);
+        if (side == 1) store_game<1>(a.state, a.gstate, N, (size_t)i, g);        // post-make, pre-settle
+        a.xout[i] = split_settle(cx, g);
+        store_game<1>(side == 1 ? a.shadow : a.state, a.gstate, N, (size_t)i, g);
+    } else if (STAGE == 1) {
+        uint32_t w;
+        if (side == 0) {
+            const bool i_died = (my_a & XW_DIED) != 0;
+            const int in = (!i_died && (opp_a & XW_RAN) && !(opp_a & XW_DIED)) ? xw_sent(opp_a) : 0;
+            w = split_tick(cx, g, a.ms, in);
+        } else {
+            const uint32_t opp_b = a.xw[(size_t)2 * a.n + i];
+            const int in1 = ((opp_a & XW_RAN) && !(opp_a & XW_DIED)) ? xw_sent(opp_a) : 0;
+            if (!g.round_over && in1 > 0) q.incoming = q.incoming + (float)in1 / 1.0f;   // loop 1, PythonHandle.cpp:121
+            const int in2 = (opp_b & XW_DIED) ? 0 : xw_sent(opp_b);                      // loop 2, :175
+            w = split_tick(cx, g, a.ms, in2);
+        }
+        a.xout[i] = w;
+        store_game<1>(a.state, a.gstate, N, (size_t)i, g);
+    } else {
+        const uint32_t opp_b = a.xw[(size_t)(side == 0 ? 3 : 2) * a.n + i];
+        const int in = (side == 0 && !(opp_b & XW_DIED)) ? xw_sent(opp_b) : 0;
+        const int done = split_finish(g, in, (opp_b & XW_DEAD_NOW) != 0);
+        if (a.done) a.done[i] = (uint8_t)done;
+        if (a.lines) a.lines[i] = (uint8_t)q.reward;
+        if (a.dead) a.dead[i] = (uint8_t)q.dead;
+        store_game<1>(a.state, a.gstate, N, (size_t)i, g);
+    }
     if (g.status) {
 #if defined(__HIP_DEVICE_COMPILE__)
         atomicOr(a.status, g.status);

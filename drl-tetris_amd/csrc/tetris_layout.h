@@ -47,7 +47,7 @@ enum Word : int {
 };
 
 enum GameWord : int {
-    G_META = 0,     // seed16[0:16) round_over[16] last_winner+1[17:21)
+    G_META = 0,     // seed16[0:16) round_over[16] last_winner+1[17:21) | split mode: side[21] opp_dead[22] split[23]
     G_EPISODE = 1,  // episodes finished by the built-in rollout (SURVEY.md §8d seed schedule)
     G_LINES = 2,    // lines cleared during built-in rollouts (cumulative; summed by k_totals)
     G_SENT = 3,     // garbage lines sent during built-in rollouts (cumulative)

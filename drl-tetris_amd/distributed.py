@@ -66,3 +66,72 @@ class ShardedRollout:
 
     def close(self):
         self.batch.close()
+
+
+class SplitOpponents:
+    """Cross-device opponents (BASELINE config 5): this rank holds ONE player (`side`) of n_games two-player games,
+    rank `peer` holds the other player of the same games.  The garbage-line exchange of the reference
+    (PythonHandle::distributeLines, PythonHandle.cpp:124-136) and the dead flags of its winner logic become three
+    all-gathers of one 32-bit word per board per step (stage protocol: csrc/tetris_engine.h "split mode").
+
+    With the `nccl` backend (= RCCL over xGMI) every buffer is a device tensor and the batch runs on torch's current
+    stream, so kernels and collectives are stream-ordered without host synchronisation.  With `gloo` (CPU tests, where
+    the library is the CPU test harness) the same code runs on host tensors.
+    """
+
+    def __init__(self, n_games, side, peer, dist, height=20, width=10, pieces=(0, 1, 2, 3, 4, 5, 6), seeds=None, device=0,
+                 lib_path=None):
+        import torch
+
+        self.torch, self.dist = torch, dist
+        self.n, self.side, self.peer = int(n_games), int(side), int(peer)
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.on_gpu = dist.get_backend() == "nccl"
+        self.dev = torch.device("cuda", device) if self.on_gpu else torch.device("cpu")
+        self.batch = TetrisBatch(n_games, 1, height, width, pieces=pieces, seeds=seeds, device=device, lib_path=lib_path,
+                                 split_side=side)
+        if self.on_gpu:
+            self.batch.set_stream(torch.cuda.current_stream(self.dev).cuda_stream)
+        z = lambda *shape, dt=torch.uint8: torch.zeros(*shape, dtype=dt, device=self.dev)
+        self.rot, self.trans, self.acting = z(self.n), z(self.n), z(self.n)
+        self.done, self.lines, self.dead = z(self.n), z(self.n), z(self.n)
+        self.words = z(4, self.n, dt=torch.int32)          # my A, opponent's A, player 0's B, player 1's B
+        self.out = z(self.n, dt=torch.int32)
+        self.gathered = z(self.world, self.n, dt=torch.int32)
+
+    def _exchange(self, mine):
+        self.dist.all_gather_into_tensor(self.gathered.view(-1), mine)
+        return self.gathered[self.peer]
+
+    def step_rt(self, rot, trans, acting, ms=400):
+        """One env-step of all games: player acting[g] of game g plays (rot[g], trans[g]).  -> done, lines, dead (numpy, my side)."""
+        t = self.torch
+        for dst, src in ((self.rot, rot), (self.trans, trans), (self.acting, acting)):
+            dst.copy_(t.as_tensor(np.ascontiguousarray(src, dtype=np.uint8)), non_blocking=True)
+        B, w = self.batch, self.words
+        B.split_stage(0, rot=self.rot.data_ptr(), trans=self.trans.data_ptr(), acting=self.acting.data_ptr(), out=self.out.data_ptr(), ms=ms)
+        w[0].copy_(self.out)
+        w[1].copy_(self._exchange(self.out))                                   # exchange 1: loop-1 results
+        zero = t.zeros_like(self.out)
+        if self.side == 0:
+            B.split_stage(1, words=w.data_ptr(), out=self.out.data_ptr(), ms=ms)
+            w[2].copy_(self.out)
+            self._exchange(self.out)                                           # exchange 2: player 0's tick
+            w[3].copy_(self._exchange(zero))                                   # exchange 3: player 1's tick
+        else:
+            w[2].copy_(self._exchange(zero))
+            B.split_stage(1, words=w.data_ptr(), out=self.out.data_ptr(), ms=ms)
+            w[3].copy_(self.out)
+            self._exchange(self.out)
+        B.split_stage(2, words=w.data_ptr(), done=self.done.data_ptr(), lines=self.lines.data_ptr(), dead=self.dead.data_ptr(), ms=ms)
+        if self.on_gpu:
+            t.cuda.current_stream(self.dev).synchronize()
+        return self.done.cpu().numpy().copy(), self.lines.cpu().numpy().copy(), self.dead.cpu().numpy().copy()
+
+    def reset(self, idx, seeds):
+        if self.on_gpu:
+            self.torch.cuda.current_stream(self.dev).synchronize()
+        self.batch.reset(idx, seeds)
+
+    def close(self):
+        self.batch.close()

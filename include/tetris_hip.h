@@ -162,6 +162,27 @@ int tetris_rollout_random(tetris_batch *b, int launches, int steps_per_launch, u
  * games (the reference's equivalent: N worker containers, docker-compose.yaml:27).               */
 int tetris_set_game_offset(tetris_batch *b, uint64_t first_game_id);
 
+/* ---- split mode: the two players of a game on different GPUs (BASELINE config 5) ------------------------------
+ * A split batch holds ONE side (player index `side`, 0 or 1) of n_games two-player games; the batch holding the
+ * other side is normally on another GPU and created with the same seeds.  A step is three stages with one 32-bit
+ * exchange word per board after each; the caller moves the words (RCCL all-gather in drl-tetris_amd/distributed.py).
+ * replaces: PythonHandle::distributeLines + the winner logic across players (PythonHandle.cpp:124-136,151-187).
+ *   stage 0: key interpreter for the acting side ([8]*r+[2]+[3]*t+[7]) + loop 1 (side 1 speculatively) -> words A
+ *   stage 1: delayCheck of my player.  Side 0 runs it after the A exchange, side 1 after player 0's B words arrived
+ *   stage 2: lines arriving after my tick, winner / round_over -> done[n], lines[n], dead[n] (any may be NULL)
+ * d_words [4][n] uint32 (device): row 0 my A words, row 1 the opponent's A words, row 2 player 0's B words, row 3
+ * player 1's B words (rows not yet exchanged are not read).  d_out [n]: this stage's words (stages 0, 1).
+ * All pointers are device pointers; everything is enqueued on the batch's stream.  tetris_reset() on a split batch
+ * applies the two-player winner rule.                                                                            */
+int tetris_create_split(tetris_batch **out, int n_games, int side, int height, int width,
+                        const uint8_t piece_map[7], int device, const int16_t *seeds);
+int tetris_split_stage_dev(tetris_batch *b, int stage, const uint8_t *d_rot, const uint8_t *d_trans,
+                           const uint8_t *d_acting, int ms, const uint32_t *d_words, uint32_t *d_out,
+                           uint8_t *d_done, uint8_t *d_lines, uint8_t *d_dead);
+/* Run the batch on a caller-owned HIP stream (e.g. torch's current stream) so that its kernels are ordered with the
+ * caller's collectives without host synchronisation; NULL = back to the batch's own stream.                      */
+int tetris_set_stream(tetris_batch *b, void *hip_stream);
+
 /* plumbing for zero-copy callers (torch / another HIP library)                                   */
 void *tetris_device_state(tetris_batch *b);            /* uint32 [NWORDS][P][N]                  */
 void *tetris_stream(tetris_batch *b);                  /* hipStream_t                            */

@@ -71,6 +71,8 @@ struct tetris_batch {
     uint32_t status = 0;
     uint32_t margin = 64;
     uint32_t game_offset = 0;
+    int split = 0, side = 0;
+    std::vector<uint32_t> shadow;
     Tables* tab;
 };
 
@@ -150,8 +152,8 @@ void* tetris_device_state(tetris_batch* b) { return b ? b->state.data() : nullpt
 void* tetris_stream(tetris_batch*) { return nullptr; }
 int tetris_is_cpu_harness(void) { return 1; }
 
-int tetris_create(tetris_batch** out, int n_games, int n_players, int height, int width, const uint8_t piece_map[7], int,
-                  const int16_t* seeds) {
+static int create_impl(tetris_batch** out, int n_games, int n_players, int height, int width, const uint8_t piece_map[7],
+                       const int16_t* seeds, int split, int side) {
     if (!out) return fail(TETRIS_E_ARG, "out is NULL");
     *out = nullptr;
     if (n_games < 1) return fail(TETRIS_E_ARG, "n_games must be >= 1");
@@ -165,15 +167,39 @@ int tetris_create(tetris_batch** out, int n_games, int n_players, int height, in
     b->state.assign((size_t)NWORDS * n_players * n_games, 0);
     b->gstate.assign((size_t)NGWORDS * n_games, 0);
     b->tab = tables_for(piece_map);
+    b->split = split; b->side = side;
+    if (split && side == 1) b->shadow.assign((size_t)NWORDS * n_players * n_games, 0);
     KArgs a = base_args(b, n_games, nullptr);
-    a.seeds = seeds;
-    run<M_INIT>(b, a);
+    a.seeds = seeds; a.steps = side;
+    if (split) run<M_SPLIT_INIT>(b, a); else run<M_INIT>(b, a);
     int rc = finish_call(b);
     if (rc) { delete b; return rc; }
     *out = b;
     return TETRIS_OK;
 }
 
+int tetris_create(tetris_batch** out, int n_games, int n_players, int height, int width, const uint8_t piece_map[7], int,
+                  const int16_t* seeds) { return create_impl(out, n_games, n_players, height, width, piece_map, seeds, 0, 0); }
+int tetris_create_split(tetris_batch** out, int n_games, int side, int height, int width, const uint8_t piece_map[7], int,
+                        const int16_t* seeds) {
+    if (side != 0 && side != 1) return fail(TETRIS_E_ARG, "side must be 0 or 1");
+    return create_impl(out, n_games, 1, height, width, piece_map, seeds, 1, side);
+}
+int tetris_set_stream(tetris_batch*, void*) { return TETRIS_OK; }
+int tetris_split_stage_dev(tetris_batch* b, int stage, const uint8_t* rot, const uint8_t* trans, const uint8_t* acting, int ms,
+                           const uint32_t* words, uint32_t* outw, uint8_t* done, uint8_t* lines, uint8_t* dead) {
+    if (!b->split) return fail(TETRIS_E_ARG, "not a split batch");
+    if (stage < 0 || stage > 2) return fail(TETRIS_E_ARG, "stage");
+    KArgs a = base_args(b, b->N, nullptr);
+    a.rot = rot; a.trans = trans; a.player = acting; a.ms = ms;
+    a.shadow = b->shadow.data(); a.xw = words; a.xout = outw; a.done = done; a.lines = lines; a.dead = dead;
+    for (int i = 0; i < b->N; i++) {
+        if (stage == 0) split_body<0>(a, i, SHAPES.s);
+        else if (stage == 1) split_body<1>(a, i, SHAPES.s);
+        else split_body<2>(a, i, SHAPES.s);
+    }
+    return TETRIS_OK;
+}
 int tetris_destroy(tetris_batch* b) { delete b; return TETRIS_OK; }
 int tetris_sync(tetris_batch* b) { return finish_call(b); }
 int tetris_set_game_offset(tetris_batch* b, uint64_t first) { b->game_offset = (uint32_t)first; return TETRIS_OK; }
@@ -187,7 +213,7 @@ static int check_idx(tetris_batch* b, const int32_t* idx, int n) {
 int tetris_reset(tetris_batch* b, const int32_t* idx, int n, const int16_t* seeds) {
     int rc = check_idx(b, idx, n); if (rc) return rc;
     KArgs a = base_args(b, n, idx); a.seeds = seeds;
-    run<M_RESET>(b, a);
+    if (b->split) run<M_SPLIT_RESET>(b, a); else run<M_RESET>(b, a);
     return finish_call(b);
 }
 
