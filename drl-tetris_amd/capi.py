@@ -49,6 +49,7 @@ _SIGNATURES = {
     "tetris_snapshot_words": (C.c_int, [C.c_void_p]),
     "tetris_table_chunks": (C.c_int, [C.c_void_p]),
     "tetris_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "tetris_create_ex": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
     "tetris_destroy": (C.c_int, [C.c_void_p]),
     "tetris_sync": (C.c_int, [C.c_void_p]),
     "tetris_set_game_offset": (C.c_int, [C.c_void_p, C.c_uint64]),
@@ -109,8 +110,9 @@ class TetrisBatch:
     """N games resident on one GPU (one `tetris_batch`)."""
 
     def __init__(self, n_games, n_players=2, height=20, width=10, pieces=(0, 1, 2, 3, 4, 5, 6), seeds=None, device=0, lib_path=None,
-                 split_side=None):
-        """split_side = 0 / 1: this batch holds only that player of n_games two-player games (opponents on another GPU)."""
+                 split_side=None, colours=False):
+        """split_side = 0 / 1: this batch holds only that player of n_games two-player games (opponents on another GPU).
+        colours: also track tile values, so that records hold the reference's exact State.field (1..7 tiles, 8 garbage)."""
         self.lib = load_library(lib_path)
         self.split_side = split_side
         if split_side is not None:
@@ -119,9 +121,10 @@ class TetrisBatch:
         self.piece_map = np.array((list(pieces) * 7)[:7], dtype=np.uint8)      # tetris_environment.py:191-193
         self._h = C.c_void_p()
         s = self._seeds(seeds, self.n_games) if seeds is not None else None
+        self.colours = bool(colours)
         if split_side is None:
-            self._check(self.lib.tetris_create(C.byref(self._h), self.n_games, self.n_players, self.height, self.width,
-                                               _p(self.piece_map), int(device), _p(s)))
+            self._check(self.lib.tetris_create_ex(C.byref(self._h), self.n_games, self.n_players, self.height, self.width,
+                                                  _p(self.piece_map), int(device), _p(s), 1 if colours else 0))
         else:
             self._check(self.lib.tetris_create_split(C.byref(self._h), self.n_games, int(split_side), self.height, self.width,
                                                      _p(self.piece_map), int(device), _p(s)))

@@ -97,11 +97,13 @@ struct Ctx {
     uint32_t margin;                 // ST_NEED_EXTEND when a draw counter comes this close to n_draws
     int H;
     uint32_t floor_bits;             // ~0u << H
+    bool tint;                       // colour planes are tracked (compile-time constant in every kernel)
 };
 
 // ---------------------------------------------------------------- one player-board in registers
 struct Player {
     uint32_t col[NCOL];
+    uint32_t tint[3][NCOL];          // colour planes (only touched when Ctx::tint)
     int kind, rot, x, y, next;
     int dead, lock_armed, reward;
     int inc_count, combo_count, line_count, qlen, q_overflow;
@@ -135,7 +137,7 @@ struct Game {
 // ---------------------------------------------------------------- load / store (SoA, coalesced)
 // state[(w * P + p) * n + slot]; game words at gstate[w * n + slot]
 template <int P>
-TE_HD void load_game(const uint32_t* state, const uint32_t* gstate, size_t n, size_t slot, Game<P>& g) {
+TE_HD void load_game(const uint32_t* state, const uint32_t* gstate, size_t n, size_t slot, Game<P>& g, bool tint = false) {
     uint32_t meta = ld_stream(&gstate[(size_t)G_META * n + slot]);
     g.seed16 = meta & 0xFFFFu;
     g.round_over = (meta >> 16) & 1;
@@ -151,6 +153,9 @@ TE_HD void load_game(const uint32_t* state, const uint32_t* gstate, size_t n, si
         const uint32_t* s = state + (size_t)p * n + slot;
         const size_t ws = (size_t)P * n;
         for (int c = 0; c < NCOL; c++) q.col[c] = ld_stream(&s[(size_t)(W_COL0 + c) * ws]);
+        if (tint)
+            for (int k = 0; k < 3; k++)
+                for (int c = 0; c < NCOL; c++) q.tint[k][c] = ld_stream(&s[(size_t)(W_TINT0 + 10 * k + c) * ws]);
         uint32_t w = ld_stream(&s[(size_t)W_PIECE * ws]);
         q.kind = w & 7; q.rot = (w >> 3) & 3; q.x = (int)((w >> 5) & 15) - 4; q.y = (w >> 9) & 31;
         q.next = (w >> 14) & 7; q.dead = (w >> 17) & 1; q.lock_armed = (w >> 18) & 1; q.reward = (w >> 19) & 255;
@@ -187,7 +192,7 @@ TE_HD void load_game(const uint32_t* state, const uint32_t* gstate, size_t n, si
 }
 
 template <int P>
-TE_HD void store_game(uint32_t* state, uint32_t* gstate, size_t n, size_t slot, const Game<P>& g) {
+TE_HD void store_game(uint32_t* state, uint32_t* gstate, size_t n, size_t slot, const Game<P>& g, bool tint = false) {
     st_stream(&gstate[(size_t)G_META * n + slot], g.seed16 | ((uint32_t)g.round_over << 16) | ((uint32_t)(g.last_winner + 1) << 17) | (g.flags << 21));
     st_stream(&gstate[(size_t)G_EPISODE * n + slot], g.episode);
     st_stream(&gstate[(size_t)G_LINES * n + slot], g.roll_lines);
@@ -198,6 +203,9 @@ TE_HD void store_game(uint32_t* state, uint32_t* gstate, size_t n, size_t slot, 
         uint32_t* s = state + (size_t)p * n + slot;
         const size_t ws = (size_t)P * n;
         for (int c = 0; c < NCOL; c++) st_stream(&s[(size_t)(W_COL0 + c) * ws], q.col[c]);
+        if (tint)
+            for (int k = 0; k < 3; k++)
+                for (int c = 0; c < NCOL; c++) st_stream(&s[(size_t)(W_TINT0 + 10 * k + c) * ws], q.tint[k][c]);
         st_stream(&s[(size_t)W_PIECE * ws], (uint32_t)q.kind | ((uint32_t)q.rot << 3) | ((uint32_t)(q.x + 4) << 5) | ((uint32_t)q.y << 9) |
                                   ((uint32_t)q.next << 14) | ((uint32_t)q.dead << 17) | ((uint32_t)q.lock_armed << 18) |
                                   ((uint32_t)(q.reward & 255) << 19));
@@ -279,12 +287,17 @@ TE_HD int drop_distance(const Ctx& cx, const Player& q, uint32_t shape) {
     return dist == 64 ? 0 : dist;
 }
 
-// gameField.cpp:105-110 addPiece (occupancy only)
-TE_HD void stamp(Player& q, uint32_t shape) {
+// gameField.cpp:105-110 addPiece: the four squares become occupied and take the piece's tile value (kind + 1)
+TE_HD void stamp(const Ctx& cx, Player& q, uint32_t shape) {
     unsigned xs = (unsigned)(q.x + 2);
     if (xs > 12u) return;
     uint64_t placed = (uint64_t)(shape & 0xFFFFu) << (4 * xs);
-    for (int c = 0; c < NCOL; c++) q.col[c] |= ((uint32_t)(placed >> (4 * c + 8)) & 0xFu) << q.y;
+    for (int c = 0; c < NCOL; c++) {
+        const uint32_t cells = ((uint32_t)(placed >> (4 * c + 8)) & 0xFu) << q.y;
+        q.col[c] |= cells;
+        if (cx.tint)
+            for (int k = 0; k < 3; k++) q.tint[k][c] = (q.tint[k][c] & ~cells) | (((q.kind >> k) & 1) ? cells : 0u);
+    }
 }
 
 // gameField.cpp:120-145 clearlines (+ removeline :112-118): rows >= piece.posY that are full are
@@ -300,6 +313,13 @@ TE_HD int clear_rows(const Ctx& cx, Player& q) {
         int r = 31 - clz32(full);
         uint32_t above = (1u << r) - 1u;            // rows 0..r-1
         uint32_t keep = ~((above << 1) | 1u);       // rows r+1..
+        if (cx.tint) {
+            uint32_t garbage = 0;                   // squares holding an 8 (value - 1 = 0b111)
+            for (int c = 0; c < NCOL; c++) garbage |= q.col[c] & q.tint[0][c] & q.tint[1][c] & q.tint[2][c];
+            if ((garbage >> r) & 1u) q.garbage_cleared = (q.garbage_cleared + 1u) & 0xFFFFu;       // gameField.cpp:128-129,140-141
+            for (int k = 0; k < 3; k++)
+                for (int c = 0; c < NCOL; c++) q.tint[k][c] = (q.tint[k][c] & keep) | ((q.tint[k][c] & above) << 1);
+        }
         for (int c = 0; c < NCOL; c++) q.col[c] = (q.col[c] & keep) | ((q.col[c] & above) << 1);
         cleared++;
     }
@@ -430,7 +450,7 @@ TE_HD bool spawn_next(const Ctx& cx, Player& q, uint32_t seed16, uint32_t& statu
     q.next = (int)(byte & 7u);
     q.piece_draws++;
     uint32_t shape = shape_of(cx, q.kind, q.rot);
-    if (!fits_at(cx, q, shape, q.x, 0)) { stamp(q, shape); return true; }
+    if (!fits_at(cx, q, shape, q.x, 0)) { stamp(cx, q, shape); return true; }
     return false;
 }
 
@@ -448,7 +468,7 @@ TE_HD int score_clears(Player& q, int cleared) {
 TE_HD void lock_piece(const Ctx& cx, Player& q) {
     uint32_t shape = shape_of(cx, q.kind, q.rot);
     q.y += drop_distance(cx, q, shape);
-    stamp(q, shape);
+    stamp(cx, q, shape);
     q.drop_time = q.time_ms;
     q.lock_armed = 0;
 }
@@ -496,6 +516,9 @@ TE_HD bool push_garbage(const Ctx& cx, Player& q, uint32_t seed16, uint32_t& sta
     q.hole_draws++;
     uint32_t bottom = 1u << (cx.H - 1);
     for (int c = 0; c < NCOL; c++) q.col[c] = (q.col[c] >> 1) | (c == hole ? 0u : bottom);
+    if (cx.tint)
+        for (int k = 0; k < 3; k++)
+            for (int c = 0; c < NCOL; c++) q.tint[k][c] = (q.tint[k][c] >> 1) | (c == hole ? 0u : bottom);
     if (q.y > 0) q.y--;
     if (!fits_at(cx, q, shape_of(cx, q.kind, q.rot), q.x, q.y)) {
         if (q.y > 0) q.y--;
@@ -532,6 +555,9 @@ TE_HD int tick(const Ctx& cx, Player& q, int ms, uint32_t seed16, uint32_t& stat
 // Not reset (as in the reference): reward, inc_count, combo_remaining.
 TE_HD void restart_player(const Ctx& cx, Player& q, uint32_t seed16, uint32_t& status, const ResetPrefetch* pf = nullptr) {
     for (int c = 0; c < NCOL; c++) q.col[c] = 0;
+    if (cx.tint)
+        for (int k = 0; k < 3; k++)
+            for (int c = 0; c < NCOL; c++) q.tint[k][c] = 0;
     q.qlen = 0; q.q_overflow = 0; q.lines_blocked = 0; q.min_remaining = 1000;
     for (int i = 0; i < FIFO_CAP; i++) { q.qcount[i] = 0; q.qdelay[i] = 0; }
     q.combo_start = 0; q.combo_time = 0; q.max_combo = 0; q.combo_count = 0; q.line_count = 0;
@@ -711,7 +737,7 @@ TE_HD void play_rt(const Ctx& cx, Player& q, int r, int t) {
     q.x = xs - 2;
     // gamePlay.cpp:48-52 hd_make
     q.y += drop_distance(cx, q, shape);
-    stamp(q, shape);
+    stamp(cx, q, shape);
     q.drop_time = q.time_ms;
     q.lock_armed = 0;
 }

@@ -22,17 +22,17 @@ using namespace te;
 
 __device__ const ShapeTable d_shape_table = make_shape_table();
 
-template <int P, int MODE>
+template <int P, int MODE, bool TINT>
 __global__ __launch_bounds__(256) void k_game(KArgs a) {
     __shared__ __attribute__((aligned(16))) uint32_t s_shapes[32];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool active = i < a.n;
     LaneCounters cnt = {0, 0, 0, 0};                   // (per-lane sums feed the CPU test harness only)
     Game<P> g;
-    if (active) game_load<P, MODE>(a, i, g);          // state loads in flight ...
+    if (active) game_load<P, MODE, TINT>(a, i, g);          // state loads in flight ...
     if (threadIdx.x < 32) s_shapes[threadIdx.x] = d_shape_table.s[threadIdx.x];
     __syncthreads();                                   // ... while the shape table lands in LDS
-    if (active) game_run<P, MODE>(a, i, s_shapes, g, cnt);
+    if (active) game_run<P, MODE, TINT>(a, i, s_shapes, g, cnt);
 }
 
 // Sums the per-game cumulative rollout counters (G_EPISODE, G_LINES, G_SENT): run once before and once
@@ -52,13 +52,13 @@ __global__ __launch_bounds__(256) void k_totals(const uint32_t* gstate, int n_ga
     }
 }
 
-template <int STAGE>
+template <int STAGE, bool TINT>
 __global__ __launch_bounds__(256) void k_split(KArgs a) {
     __shared__ __attribute__((aligned(16))) uint32_t s_shapes[32];
     if (threadIdx.x < 32) s_shapes[threadIdx.x] = d_shape_table.s[threadIdx.x];
     __syncthreads();
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < a.n) split_body<STAGE>(a, i, s_shapes);
+    if (i < a.n) split_body<STAGE, TINT>(a, i, s_shapes);
 }
 
 // ---- RNG tables: one lane per 16-bit seed, MT state strided [word][seed] (coalesced)
@@ -80,12 +80,12 @@ __global__ __launch_bounds__(256) void k_gen_chunk(uint32_t* mt, float* w, uint8
     if (chunk == 0) start[seed] = word;
 }
 
-template <int P>
+template <int P, bool TINT>
 __global__ __launch_bounds__(256) void k_observe(const uint32_t* state, const uint32_t* gstate, int n_games, int n,
                                                  const int32_t* idx, int H, tetris_record* rec, uint8_t* round_over,
                                                  int8_t* last_winner) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) observe_body<P>(state, gstate, n_games, i, idx, H, d_shape_table.s, rec, round_over, last_winner);
+    if (i < n) observe_body<P, TINT>(state, gstate, n_games, i, idx, H, d_shape_table.s, rec, round_over, last_winner);
 }
 
 // Observation kernel: one lane reads its board's ten column words (coalesced SoA), expands them to H*10 bytes
@@ -143,9 +143,9 @@ __global__ __launch_bounds__(64) void k_actions(const uint32_t* state, int n_gam
 }
 
 __global__ __launch_bounds__(256) void k_snapshot(uint32_t* state, uint32_t* gstate, int n_games, int n, const int32_t* idx,
-                                                  int P, uint32_t* blob, int restore) {
+                                                  int P, uint32_t* blob, int restore, int nw) {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < (size_t)n * (NGWORDS + P * NWORDS)) snapshot_body(state, gstate, n_games, t, idx, P, blob, restore);
+    if (t < (size_t)n * (NGWORDS + P * nw)) snapshot_body(state, gstate, n_games, t, idx, P, blob, restore, nw);
 }
 
 __global__ __launch_bounds__(256) void k_set_dead(uint32_t* state, int n_games, int n, const int32_t* idx, int P,
@@ -285,6 +285,7 @@ struct tetris_batch {
     uint32_t margin = 64;
     uint32_t game_offset = 0;
     int split = 0, side = 0;
+    int tint = 0, nw = NWORDS;           // colour planes tracked; words per player-board
     uint32_t* d_shadow = nullptr;        // split mode, side 1
     hipStream_t own_stream = nullptr;
     Stage s_idx, s_in0, s_in1, s_in2, s_out0, s_out1, s_out2, s_big;
@@ -303,8 +304,10 @@ static KArgs base_args(tetris_batch* b, int n, const int32_t* d_idx) {
 template <int MODE>
 static int launch_game(tetris_batch* b, const KArgs& a) {
     dim3 grid((unsigned)((a.n + 255) / 256)), block(256);
-    if (b->P == 1) hipLaunchKernelGGL((k_game<1, MODE>), grid, block, 0, b->stream, a);
-    else hipLaunchKernelGGL((k_game<2, MODE>), grid, block, 0, b->stream, a);
+    if (b->P == 1 && !b->tint) hipLaunchKernelGGL((k_game<1, MODE, false>), grid, block, 0, b->stream, a);
+    else if (b->P == 1) hipLaunchKernelGGL((k_game<1, MODE, true>), grid, block, 0, b->stream, a);
+    else if (!b->tint) hipLaunchKernelGGL((k_game<2, MODE, false>), grid, block, 0, b->stream, a);
+    else hipLaunchKernelGGL((k_game<2, MODE, true>), grid, block, 0, b->stream, a);
     HIP_TRY(hipGetLastError());
     return TETRIS_OK;
 }
@@ -373,7 +376,7 @@ int tetris_device_count(void) {
 
 int tetris_record_size(void) { return (int)sizeof(tetris_record); }
 int tetris_layout_words(void) { return NWORDS; }
-int tetris_snapshot_words(const tetris_batch* b) { return b ? NGWORDS + b->P * NWORDS : 0; }
+int tetris_snapshot_words(const tetris_batch* b) { return b ? NGWORDS + b->P * b->nw : 0; }
 int tetris_table_chunks(const tetris_batch* b) { return b && b->tab ? b->tab->n_chunks : 0; }
 void* tetris_device_state(tetris_batch* b) { return b ? b->d_state : nullptr; }
 void* tetris_stream(tetris_batch* b) { return b ? (void*)b->stream : nullptr; }
@@ -395,7 +398,7 @@ int tetris_destroy(tetris_batch* b) {
 }
 
 static int create_impl(tetris_batch** out, int n_games, int n_players, int height, int width, const uint8_t piece_map[7],
-                       int device, const int16_t* seeds, int split, int side) {
+                       int device, const int16_t* seeds, int split, int side, int flags = 0) {
     if (!out) return fail(TETRIS_E_ARG, "out is NULL");
     *out = nullptr;
     if (n_games < 1) return fail(TETRIS_E_ARG, "n_games must be >= 1");
@@ -415,6 +418,8 @@ static int create_impl(tetris_batch** out, int n_games, int n_players, int heigh
     tetris_batch* b = new (std::nothrow) tetris_batch();
     if (!b) return fail(TETRIS_E_HIP, "out of host memory");
     b->device = device; b->N = n_games; b->P = n_players; b->H = height;
+    b->tint = (flags & TETRIS_FLAG_COLOURS) ? 1 : 0;
+    b->nw = b->tint ? NWORDS_TINT : NWORDS;
 #define CREATE_TRY(expr)                                                                    \
     do {                                                                                    \
         hipError_t e_ = (expr);                                                             \
@@ -427,14 +432,14 @@ static int create_impl(tetris_batch** out, int n_games, int n_players, int heigh
     b->own_stream = b->stream;
     CREATE_TRY(hipEventCreate(&b->ev0));
     CREATE_TRY(hipEventCreate(&b->ev1));
-    CREATE_TRY(hipMalloc((void**)&b->d_state, (size_t)NWORDS * n_players * n_games * 4));
+    CREATE_TRY(hipMalloc((void**)&b->d_state, (size_t)b->nw * n_players * n_games * 4));
     CREATE_TRY(hipMalloc((void**)&b->d_gstate, (size_t)NGWORDS * n_games * 4));
     CREATE_TRY(hipMalloc((void**)&b->d_status, 16));
     CREATE_TRY(hipMalloc((void**)&b->d_counters, 8 * sizeof(unsigned long long)));
     CREATE_TRY(hipHostMalloc((void**)&b->h_status, 128, hipHostMallocDefault));
     CREATE_TRY(hipMemsetAsync(b->d_status, 0, 16, b->stream));
     CREATE_TRY(hipMemsetAsync(b->d_gstate, 0, (size_t)NGWORDS * n_games * 4, b->stream));
-    CREATE_TRY(hipMemsetAsync(b->d_state, 0, (size_t)NWORDS * n_players * n_games * 4, b->stream));
+    CREATE_TRY(hipMemsetAsync(b->d_state, 0, (size_t)b->nw * n_players * n_games * 4, b->stream));
     int rc = tables_acquire(&b->tab, device, piece_map, b->stream);
     if (rc) { std::string keep = g_err; tetris_destroy(b); return fail(rc, keep); }
     const int16_t* d_seeds = nullptr;
@@ -444,7 +449,7 @@ static int create_impl(tetris_batch** out, int n_games, int n_players, int heigh
         d_seeds = (const int16_t*)b->s_in0.d;
     }
     b->split = split; b->side = side;
-    if (split && side == 1) CREATE_TRY(hipMalloc((void**)&b->d_shadow, (size_t)NWORDS * n_players * n_games * 4));
+    if (split && side == 1) CREATE_TRY(hipMalloc((void**)&b->d_shadow, (size_t)b->nw * n_players * n_games * 4));
     KArgs a = base_args(b, n_games, nullptr);
     a.seeds = d_seeds;
     a.steps = side;
@@ -464,6 +469,12 @@ int tetris_set_game_offset(tetris_batch* b, uint64_t first_game_id) {
 int tetris_create(tetris_batch** out, int n_games, int n_players, int height, int width, const uint8_t piece_map[7],
                   int device, const int16_t* seeds) {
     return create_impl(out, n_games, n_players, height, width, piece_map, device, seeds, 0, 0);
+}
+
+int tetris_create_ex(tetris_batch** out, int n_games, int n_players, int height, int width, const uint8_t piece_map[7], int device,
+                     const int16_t* seeds, int flags) {
+    if (flags & ~TETRIS_FLAG_COLOURS) return fail(TETRIS_E_ARG, "unknown flag");
+    return create_impl(out, n_games, n_players, height, width, piece_map, device, seeds, 0, 0, flags);
 }
 
 int tetris_create_split(tetris_batch** out, int n_games, int side, int height, int width, const uint8_t piece_map[7], int device,
@@ -493,9 +504,9 @@ int tetris_split_stage_dev(tetris_batch* b, int stage, const uint8_t* d_rot, con
     a.rot = d_rot; a.trans = d_trans; a.player = d_acting; a.ms = ms;
     a.shadow = b->d_shadow; a.xw = d_words; a.xout = d_out; a.done = d_done; a.lines = d_lines; a.dead = d_dead;
     dim3 grid((unsigned)((b->N + 255) / 256)), block(256);
-    if (stage == 0) hipLaunchKernelGGL(k_split<0>, grid, block, 0, b->stream, a);
-    else if (stage == 1) hipLaunchKernelGGL(k_split<1>, grid, block, 0, b->stream, a);
-    else hipLaunchKernelGGL(k_split<2>, grid, block, 0, b->stream, a);
+    if (stage == 0) hipLaunchKernelGGL((k_split<0, false>), grid, block, 0, b->stream, a);
+    else if (stage == 1) hipLaunchKernelGGL((k_split<1, false>), grid, block, 0, b->stream, a);
+    else hipLaunchKernelGGL((k_split<2, false>), grid, block, 0, b->stream, a);
     HIP_TRY(hipGetLastError());
     return TETRIS_OK;
 }
@@ -660,12 +671,14 @@ int tetris_observe_records(tetris_batch* b, const int32_t* idx, int n, tetris_re
     dim3 grid((unsigned)((n + 255) / 256)), block(256);
     tetris_record* d_rec = (tetris_record*)b->s_big.d;
     HIP_TRY(hipMemsetAsync(d_rec, 0, rec_bytes, b->stream));      // struct padding stays deterministic
-    if (b->P == 1)
-        hipLaunchKernelGGL(k_observe<1>, grid, block, 0, b->stream, b->d_state, b->d_gstate, b->N, n, d_idx, b->H, d_rec,
-                           (uint8_t*)b->s_out0.d, (int8_t*)b->s_out1.d);
-    else
-        hipLaunchKernelGGL(k_observe<2>, grid, block, 0, b->stream, b->d_state, b->d_gstate, b->N, n, d_idx, b->H, d_rec,
-                           (uint8_t*)b->s_out0.d, (int8_t*)b->s_out1.d);
+#define LAUNCH_OBSERVE(PP, TT)                                                                                              \
+    hipLaunchKernelGGL((k_observe<PP, TT>), grid, block, 0, b->stream, b->d_state, b->d_gstate, b->N, n, d_idx, b->H, d_rec, \
+                       (uint8_t*)b->s_out0.d, (int8_t*)b->s_out1.d)
+    if (b->P == 1 && !b->tint) LAUNCH_OBSERVE(1, false);
+    else if (b->P == 1) LAUNCH_OBSERVE(1, true);
+    else if (!b->tint) LAUNCH_OBSERVE(2, false);
+    else LAUNCH_OBSERVE(2, true);
+#undef LAUNCH_OBSERVE
     HIP_TRY(hipGetLastError());
     if (records) HIP_TRY(hipMemcpyAsync(b->s_big.h, b->s_big.d, rec_bytes, hipMemcpyDeviceToHost, b->stream));
     HIP_TRY(hipMemcpyAsync(b->s_out0.h, b->s_out0.d, (size_t)n, hipMemcpyDeviceToHost, b->stream));
@@ -733,7 +746,7 @@ static int snapshot_impl(tetris_batch* b, const int32_t* idx, int n, uint32_t* b
     const int32_t* d_idx;
     if ((rc = stage_idx(b, idx, n, &d_idx))) return rc;
     if (n == 0) return TETRIS_OK;
-    const int words = NGWORDS + b->P * NWORDS;
+    const int words = NGWORDS + b->P * b->nw;
     const size_t bytes = (size_t)n * words * 4;
     if ((rc = b->s_big.ensure(bytes + 16))) return rc;
     if (restore) {
@@ -742,7 +755,7 @@ static int snapshot_impl(tetris_batch* b, const int32_t* idx, int n, uint32_t* b
     }
     size_t total = (size_t)n * words;
     hipLaunchKernelGGL(k_snapshot, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, b->stream, b->d_state, b->d_gstate,
-                       b->N, n, d_idx, b->P, (uint32_t*)b->s_big.d, restore);
+                       b->N, n, d_idx, b->P, (uint32_t*)b->s_big.d, restore, b->nw);
     HIP_TRY(hipGetLastError());
     if (!restore) HIP_TRY(hipMemcpyAsync(b->s_big.h, b->s_big.d, bytes, hipMemcpyDeviceToHost, b->stream));
     if ((rc = finish_call(b))) return rc;

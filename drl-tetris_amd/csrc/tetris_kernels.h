@@ -47,7 +47,7 @@ enum Mode { M_INIT, M_RESET, M_MAKE, M_FINISH, M_STEP_KEYS, M_STEP_RT, M_ROLLOUT
 
 struct LaneCounters { unsigned long long steps, episodes, lines, sent; };   // used by the CPU test harness only
 
-TE_HD Ctx make_ctx(const KArgs& a, const uint32_t* shapes) {
+TE_HD Ctx make_ctx(const KArgs& a, const uint32_t* shapes, bool tint = false) {
     Ctx cx;
     cx.shapes = shapes;
     cx.table = a.table;
@@ -57,6 +57,7 @@ TE_HD Ctx make_ctx(const KArgs& a, const uint32_t* shapes) {
     cx.margin = a.margin;
     cx.H = a.H;
     cx.floor_bits = ~0u << a.H;
+    cx.tint = tint;
     return cx;
 }
 
@@ -94,18 +95,18 @@ TE_HD void make_rt(const Ctx& cx, Game<P>& g, int player, int r, int t) {
 
 // Phase 1 of a lane's work: issue the state loads (nothing here needs the LDS shape table, so the
 // kernel runs this BEFORE its table-init barrier and both memory round-trips overlap).
-template <int P, int MODE>
+template <int P, int MODE, bool TINT = false>
 TE_HD void game_load(const KArgs& a, int i, Game<P>& g) {
     const size_t slot = a.idx ? (size_t)a.idx[i] : (size_t)i;
-    if (MODE != M_INIT && MODE != M_SPLIT_INIT) load_game<P>(a.state, a.gstate, (size_t)a.n_games, slot, g);
+    if (MODE != M_INIT && MODE != M_SPLIT_INIT) load_game<P>(a.state, a.gstate, (size_t)a.n_games, slot, g, TINT);
 }
 
 // Phase 2: step and store.
-template <int P, int MODE>
+template <int P, int MODE, bool TINT = false>
 TE_HD void game_run(const KArgs& a, int i, const uint32_t* shapes, Game<P>& g, LaneCounters& cnt) {
     const size_t N = (size_t)a.n_games;
     const size_t slot = a.idx ? (size_t)a.idx[i] : (size_t)i;
-    Ctx cx = make_ctx(a, shapes);
+    Ctx cx = make_ctx(a, shapes, TINT);
     if (MODE == M_INIT) init_game<P>(cx, g, (uint32_t)(a.seeds ? (uint16_t)a.seeds[i] : 0));
     if (MODE == M_SPLIT_INIT) {           // a.steps carries the side this batch holds
         init_game<P>(cx, g, (uint32_t)(a.seeds ? (uint16_t)a.seeds[i] : 0));
@@ -173,7 +174,7 @@ TE_HD void game_run(const KArgs& a, int i, const uint32_t* shapes, Game<P>& g, L
             }
         }
     }
-    store_game<P>(a.state, a.gstate, N, slot, g);
+    store_game<P>(a.state, a.gstate, N, slot, g, TINT);
     if (g.status) {
 #if defined(__HIP_DEVICE_COMPILE__)
         atomicOr(a.status, g.status);
@@ -184,10 +185,10 @@ TE_HD void game_run(const KArgs& a, int i, const uint32_t* shapes, Game<P>& g, L
 }
 
 // Split mode (opponents on different GPUs, tetris_engine.h): one stage of a step for the side this batch holds.
-template <int STAGE>
+template <int STAGE, bool TINT = false>
 TE_HD void split_body(const KArgs& a, int i, const uint32_t* shapes) {
     const size_t N = (size_t)a.n_games;
-    Ctx cx = make_ctx(a, shapes);
+    Ctx cx = make_ctx(a, shapes, TINT);
     Game<1> g;
     const uint32_t my_a = STAGE > 0 ? a.xw[i] : 0u;
     const uint32_t opp_a = STAGE > 0 ? a.xw[(size_t)a.n + i] : 0u;
@@ -195,15 +196,15 @@ TE_HD void split_body(const KArgs& a, int i, const uint32_t* shapes) {
     const uint32_t meta = a.gstate[(size_t)G_META * N + i];
     const int side = (int)((meta >> 21) & 1u);
     const bool from_shadow = STAGE == 1 && side == 1 && !(opp_a & XW_DIED);
-    load_game<1>(from_shadow ? a.shadow : a.state, a.gstate, N, (size_t)i, g);
+    load_game<1>(from_shadow ? a.shadow : a.state, a.gstate, N, (size_t)i, g, TINT);
     Player& q = g.pl[0];
     if (STAGE == 0) {
         const int acting = a.player ? a.player[i] : 0;
         prefetch_next(cx, q, g.seed16, g.status);
         if (!g.round_over && !q.dead && acting == side) play_rt(cx, q, a.rot[i] & 3, a.trans[i]);
-        if (side == 1) store_game<1>(a.state, a.gstate, N, (size_t)i, g);        // post-make, pre-settle
+        if (side == 1) store_game<1>(a.state, a.gstate, N, (size_t)i, g, TINT);        // post-make, pre-settle
         a.xout[i] = split_settle(cx, g);
-        store_game<1>(side == 1 ? a.shadow : a.state, a.gstate, N, (size_t)i, g);
+        store_game<1>(side == 1 ? a.shadow : a.state, a.gstate, N, (size_t)i, g, TINT);
     } else if (STAGE == 1) {
         uint32_t w;
         if (side == 0) {
@@ -218,7 +219,7 @@ TE_HD void split_body(const KArgs& a, int i, const uint32_t* shapes) {
             w = split_tick(cx, g, a.ms, in2);
         }
         a.xout[i] = w;
-        store_game<1>(a.state, a.gstate, N, (size_t)i, g);
+        store_game<1>(a.state, a.gstate, N, (size_t)i, g, TINT);
     } else {
         const uint32_t opp_b = a.xw[(size_t)(side == 0 ? 3 : 2) * a.n + i];
         const int in = (side == 0 && !(opp_b & XW_DIED)) ? xw_sent(opp_b) : 0;
@@ -226,7 +227,7 @@ TE_HD void split_body(const KArgs& a, int i, const uint32_t* shapes) {
         if (a.done) a.done[i] = (uint8_t)done;
         if (a.lines) a.lines[i] = (uint8_t)q.reward;
         if (a.dead) a.dead[i] = (uint8_t)q.dead;
-        store_game<1>(a.state, a.gstate, N, (size_t)i, g);
+        store_game<1>(a.state, a.gstate, N, (size_t)i, g, TINT);
     }
     if (g.status) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -237,20 +238,20 @@ TE_HD void split_body(const KArgs& a, int i, const uint32_t* shapes) {
     }
 }
 
-template <int P, int MODE>
+template <int P, int MODE, bool TINT = false>
 TE_HD void game_body(const KArgs& a, int i, const uint32_t* shapes, LaneCounters& cnt) {
     Game<P> g;
-    game_load<P, MODE>(a, i, g);
-    game_run<P, MODE>(a, i, shapes, g, cnt);
+    game_load<P, MODE, TINT>(a, i, g);
+    game_run<P, MODE, TINT>(a, i, shapes, g, cnt);
 }
 
 // State views / __getstate__ (PythonHandle.h:54-82,123-308) of one game -> P records
-template <int P>
+template <int P, bool TINT = false>
 TE_HD void observe_body(const uint32_t* state, const uint32_t* gstate, int n_games, int i, const int32_t* idx, int H,
                         const uint32_t* shapes, tetris_record* rec, uint8_t* round_over, int8_t* last_winner) {
     size_t slot = idx ? (size_t)idx[i] : (size_t)i;
     Game<P> g;
-    load_game<P>(state, gstate, (size_t)n_games, slot, g);
+    load_game<P>(state, gstate, (size_t)n_games, slot, g, TINT);
     if (round_over) round_over[i] = (uint8_t)g.round_over;
     if (last_winner) last_winner[i] = (int8_t)g.last_winner;
     if (!rec) return;
@@ -263,6 +264,10 @@ TE_HD void observe_body(const uint32_t* state, const uint32_t* gstate, int n_gam
             for (int c = 0; c < NCOL; c += 2) {
                 uint32_t lo = (y < H) ? ((q.col[c] >> y) & 1u) : 0u;
                 uint32_t hi = (y < H) ? ((q.col[c + 1] >> y) & 1u) : 0u;
+                if (TINT) {        // cell value = 1 + 3-bit plane value for occupied squares (State.field as the reference shows it)
+                    lo *= 1u + (((q.tint[0][c] >> y) & 1u) | (((q.tint[1][c] >> y) & 1u) << 1) | (((q.tint[2][c] >> y) & 1u) << 2));
+                    hi *= 1u + (((q.tint[0][c + 1] >> y) & 1u) | (((q.tint[1][c + 1] >> y) & 1u) << 1) | (((q.tint[2][c + 1] >> y) & 1u) << 2));
+                }
                 f16[(y * NCOL + c) >> 1] = (uint16_t)(lo | (hi << 8));
             }
         uint32_t shape = shapes[((q.kind & 7) << 2) | (q.rot & 3)];
@@ -331,7 +336,7 @@ TE_HD void enumerate_body(const uint32_t* state, int n_games, size_t t, const in
     const uint32_t w = s[(size_t)W_PIECE * ws];
     const int kind = w & 7, cur_rot = (w >> 3) & 3;
     Ctx cx;
-    cx.shapes = shapes; cx.H = H; cx.floor_bits = ~0u << H;
+    cx.shapes = shapes; cx.H = H; cx.floor_bits = ~0u << H; cx.tint = false;
     const int n_rot = kind == 6 ? 1 : (kind == 4 || kind == 2 || kind == 3) ? 2 : 4;     // TestField.cpp:71-109
     const int rot = kind == 6 ? cur_rot : r;                                               // O is used as it stands
     const uint32_t shape = shapes[((kind & 7) << 2) | rot];
@@ -341,7 +346,7 @@ TE_HD void enumerate_body(const uint32_t* state, int n_games, size_t t, const in
     if (ok) {
         y = drop_distance(cx, q, shape);
         q.y = y;
-        stamp(q, shape);
+        stamp(cx, q, shape);
     }
     valid[t] = ok ? 1 : 0;
     land_y[t] = (int8_t)y;
@@ -367,7 +372,7 @@ TE_HD void actions_body(const uint32_t* state, int n_games, size_t t, const int3
     const uint32_t w = s[(size_t)W_PIECE * ws];
     const int kind = w & 7, cur_rot = (w >> 3) & 3;
     Ctx cx;
-    cx.shapes = shapes; cx.H = H; cx.floor_bits = ~0u << H;
+    cx.shapes = shapes; cx.H = H; cx.floor_bits = ~0u << H; cx.tint = false;
     const int n_rot = kind == 6 ? 1 : (kind == 4 || kind == 2 || kind == 3) ? 2 : 4;
     pr.q.kind = kind; pr.q.rot = kind == 6 ? cur_rot : r; pr.q.x = xi - 1; pr.q.y = 0;
     pr.spawn = spawn_rot(kind);
@@ -394,14 +399,14 @@ TE_HD void totals_of_game(const uint32_t* gstate, int n_games, int i, unsigned l
 
 // PythonHandle.cpp:36-42 copy / set: raw words, blob[i][NGWORDS + P*NWORDS]; t = lane = (game i, word)
 TE_HD void snapshot_body(uint32_t* state, uint32_t* gstate, int n_games, size_t t, const int32_t* idx, int P, uint32_t* blob,
-                         int restore) {
-    const int words = NGWORDS + P * NWORDS;
+                         int restore, int nw = NWORDS) {
+    const int words = NGWORDS + P * nw;
     int i = (int)(t / (size_t)words), w = (int)(t % (size_t)words);
     size_t slot = idx ? (size_t)idx[i] : (size_t)i;
     uint32_t* cell;
     if (w < NGWORDS) cell = &gstate[(size_t)w * n_games + slot];
     else {
-        int pw = w - NGWORDS, p = pw / NWORDS, ww = pw % NWORDS;
+        int pw = w - NGWORDS, p = pw / nw, ww = pw % nw;
         cell = &state[((size_t)ww * P + p) * n_games + slot];
     }
     if (restore) *cell = blob[t];

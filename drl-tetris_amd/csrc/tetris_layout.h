@@ -43,7 +43,11 @@ enum Word : int {
     W_FIFO_COUNT0 = 26,    // 4 words: Garbage.count, two int16 per word
     W_FIFO_DELAY0 = 30,    // 8 words: Garbage.delay
     NWORDS = 38,
-    NWORDS_HOT = 26        // words touched by every step; the FIFO words only when a queue exists
+    NWORDS_HOT = 26,       // words touched by every step; the FIFO words only when a queue exists
+    // optional colour planes (batches created with TETRIS_FLAG_COLOURS): plane k, column c at W_TINT0 + 10 k + c holds
+    // bit k of (cell value - 1) for every occupied square: tiles 1..7 (gamePlay.cpp:146) and 8 = garbage (gamePlay.cpp:202)
+    W_TINT0 = 38,
+    NWORDS_TINT = 68
 };
 
 enum GameWord : int {

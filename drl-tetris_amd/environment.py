@@ -38,6 +38,7 @@ DEFAULT_SETTINGS = {          # the env-relevant keys of experiments/presets.py:
     "render": False,
     "render_simulation": False,
     "seed_source": None,
+    "field_colours": False,     # True: State.field holds tile values 1..8 like the reference (costs 120 B more state per board)
     "device": 0,
 }
 
@@ -77,7 +78,7 @@ class tetris_environment_vector:
         self._seed_source = s["seed_source"] or (lambda: int(time.time()))
         seed = self._seed_source()
         self.backend = TetrisBatch(n_envs, self.n_players, self.height, self.width, pieces=s["pieces"], seeds=seed,
-                                   device=s["device"], lib_path=_lib_path)
+                                   device=s["device"], lib_path=_lib_path, colours=s["field_colours"])
         self._env_ids = list(range(n_envs))
         self.done = np.zeros(n_envs, bool)
         self.rounds_played = np.zeros(n_envs, np.int64)
@@ -188,7 +189,7 @@ class tetris_environment_vector:
             return [[] for _ in idx]
         anchors = self.backend.snapshot(idx)
         scratch = TetrisBatch(total, self.n_players, self.height, self.width, pieces=self.settings["pieces"], seeds=0,
-                              device=self.settings["device"], lib_path=self._lib_path)
+                              device=self.settings["device"], lib_path=self._lib_path, colours=self.settings["field_colours"])
         scratch.restore(np.repeat(anchors, counts, axis=0))
         flat_actions = [a if type(a) is action else action(a) for al in actions for a in al]
         flat_players = [p for p, c in zip(players, counts) for _ in range(c)]

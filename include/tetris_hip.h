@@ -73,6 +73,13 @@ int         tetris_snapshot_words(const tetris_batch *b);   /* uint32 words per 
  * in for time(NULL) at construction (PythonHandle.cpp:68-71).                                   */
 int tetris_create(tetris_batch **out, int n_games, int n_players, int height, int width,
                   const uint8_t piece_map[7], int device, const int16_t *seeds);
+/* same with options.  TETRIS_FLAG_COLOURS: also track the tile value of every square (1..7 = piece index + 1,
+ * gamePlay.cpp:146; 8 = garbage, gamePlay.cpp:202) in three extra bit-planes per board, so that tetris_record.field
+ * holds exactly what the reference's State.field shows and GameplayData.garbageCleared is produced.  Costs 120 B more
+ * state per board; off by default because state_dict only uses field > 0.                                          */
+#define TETRIS_FLAG_COLOURS 1
+int tetris_create_ex(tetris_batch **out, int n_games, int n_players, int height, int width,
+                     const uint8_t piece_map[7], int device, const int16_t *seeds, int flags);
 int tetris_destroy(tetris_batch *b);
 int tetris_sync(tetris_batch *b);                      /* drain the stream, surface sticky errors */
 

@@ -72,6 +72,7 @@ struct tetris_batch {
     uint32_t margin = 64;
     uint32_t game_offset = 0;
     int split = 0, side = 0;
+    int tint = 0, nw = NWORDS;
     std::vector<uint32_t> shadow;
     Tables* tab;
 };
@@ -91,8 +92,10 @@ static void run(tetris_batch* b, const KArgs& a, LaneCounters* total = nullptr) 
     LaneCounters sum = {0, 0, 0, 0};
     for (int i = 0; i < a.n; i++) {
         LaneCounters c = {0, 0, 0, 0};
-        if (b->P == 1) game_body<1, MODE>(a, i, SHAPES.s, c);
-        else game_body<2, MODE>(a, i, SHAPES.s, c);
+        if (b->P == 1 && !b->tint) game_body<1, MODE, false>(a, i, SHAPES.s, c);
+        else if (b->P == 1) game_body<1, MODE, true>(a, i, SHAPES.s, c);
+        else if (!b->tint) game_body<2, MODE, false>(a, i, SHAPES.s, c);
+        else game_body<2, MODE, true>(a, i, SHAPES.s, c);
         sum.steps += c.steps; sum.episodes += c.episodes; sum.lines += c.lines; sum.sent += c.sent;
     }
     if (total) *total = sum;
@@ -146,14 +149,14 @@ const char* tetris_last_error(void) { return g_err.c_str(); }
 int tetris_device_count(void) { return 0; }
 int tetris_record_size(void) { return (int)sizeof(tetris_record); }
 int tetris_layout_words(void) { return NWORDS; }
-int tetris_snapshot_words(const tetris_batch* b) { return b ? NGWORDS + b->P * NWORDS : 0; }
+int tetris_snapshot_words(const tetris_batch* b) { return b ? NGWORDS + b->P * b->nw : 0; }
 int tetris_table_chunks(const tetris_batch* b) { return b ? b->tab->n_chunks : 0; }
 void* tetris_device_state(tetris_batch* b) { return b ? b->state.data() : nullptr; }
 void* tetris_stream(tetris_batch*) { return nullptr; }
 int tetris_is_cpu_harness(void) { return 1; }
 
 static int create_impl(tetris_batch** out, int n_games, int n_players, int height, int width, const uint8_t piece_map[7],
-                       const int16_t* seeds, int split, int side) {
+                       const int16_t* seeds, int split, int side, int flags = 0) {
     if (!out) return fail(TETRIS_E_ARG, "out is NULL");
     *out = nullptr;
     if (n_games < 1) return fail(TETRIS_E_ARG, "n_games must be >= 1");
@@ -164,11 +167,12 @@ static int create_impl(tetris_batch** out, int n_games, int n_players, int heigh
     for (int i = 0; i < 7; i++) if (piece_map[i] > 6) return fail(TETRIS_E_ARG, "piece_map entries must be 0..6");
     tetris_batch* b = new tetris_batch();
     b->N = n_games; b->P = n_players; b->H = height;
-    b->state.assign((size_t)NWORDS * n_players * n_games, 0);
+    b->tint = (flags & TETRIS_FLAG_COLOURS) ? 1 : 0; b->nw = b->tint ? NWORDS_TINT : NWORDS;
+    b->state.assign((size_t)b->nw * n_players * n_games, 0);
     b->gstate.assign((size_t)NGWORDS * n_games, 0);
     b->tab = tables_for(piece_map);
     b->split = split; b->side = side;
-    if (split && side == 1) b->shadow.assign((size_t)NWORDS * n_players * n_games, 0);
+    if (split && side == 1) b->shadow.assign((size_t)b->nw * n_players * n_games, 0);
     KArgs a = base_args(b, n_games, nullptr);
     a.seeds = seeds; a.steps = side;
     if (split) run<M_SPLIT_INIT>(b, a); else run<M_INIT>(b, a);
@@ -180,6 +184,11 @@ static int create_impl(tetris_batch** out, int n_games, int n_players, int heigh
 
 int tetris_create(tetris_batch** out, int n_games, int n_players, int height, int width, const uint8_t piece_map[7], int,
                   const int16_t* seeds) { return create_impl(out, n_games, n_players, height, width, piece_map, seeds, 0, 0); }
+int tetris_create_ex(tetris_batch** out, int n_games, int n_players, int height, int width, const uint8_t piece_map[7], int,
+                     const int16_t* seeds, int flags) {
+    if (flags & ~TETRIS_FLAG_COLOURS) return fail(TETRIS_E_ARG, "unknown flag");
+    return create_impl(out, n_games, n_players, height, width, piece_map, seeds, 0, 0, flags);
+}
 int tetris_create_split(tetris_batch** out, int n_games, int side, int height, int width, const uint8_t piece_map[7], int,
                         const int16_t* seeds) {
     if (side != 0 && side != 1) return fail(TETRIS_E_ARG, "side must be 0 or 1");
@@ -267,22 +276,24 @@ int tetris_observe_records(tetris_batch* b, const int32_t* idx, int n, tetris_re
                            int8_t* last_winner) {
     int rc = check_idx(b, idx, n); if (rc) return rc;
     for (int i = 0; i < n; i++) {
-        if (b->P == 1) observe_body<1>(b->state.data(), b->gstate.data(), b->N, i, idx, b->H, SHAPES.s, records, round_over, last_winner);
-        else observe_body<2>(b->state.data(), b->gstate.data(), b->N, i, idx, b->H, SHAPES.s, records, round_over, last_winner);
+        if (b->P == 1 && !b->tint) observe_body<1, false>(b->state.data(), b->gstate.data(), b->N, i, idx, b->H, SHAPES.s, records, round_over, last_winner);
+        else if (b->P == 1) observe_body<1, true>(b->state.data(), b->gstate.data(), b->N, i, idx, b->H, SHAPES.s, records, round_over, last_winner);
+        else if (!b->tint) observe_body<2, false>(b->state.data(), b->gstate.data(), b->N, i, idx, b->H, SHAPES.s, records, round_over, last_winner);
+        else observe_body<2, true>(b->state.data(), b->gstate.data(), b->N, i, idx, b->H, SHAPES.s, records, round_over, last_winner);
     }
     return TETRIS_OK;
 }
 
 int tetris_snapshot(tetris_batch* b, const int32_t* idx, int n, uint32_t* blob) {
     int rc = check_idx(b, idx, n); if (rc) return rc;
-    size_t total = (size_t)n * (NGWORDS + b->P * NWORDS);
-    for (size_t t = 0; t < total; t++) snapshot_body(b->state.data(), b->gstate.data(), b->N, t, idx, b->P, blob, 0);
+    size_t total = (size_t)n * (NGWORDS + b->P * b->nw);
+    for (size_t t = 0; t < total; t++) snapshot_body(b->state.data(), b->gstate.data(), b->N, t, idx, b->P, blob, 0, b->nw);
     return TETRIS_OK;
 }
 int tetris_restore(tetris_batch* b, const int32_t* idx, int n, const uint32_t* blob) {
     int rc = check_idx(b, idx, n); if (rc) return rc;
-    size_t total = (size_t)n * (NGWORDS + b->P * NWORDS);
-    for (size_t t = 0; t < total; t++) snapshot_body(b->state.data(), b->gstate.data(), b->N, t, idx, b->P, (uint32_t*)blob, 1);
+    size_t total = (size_t)n * (NGWORDS + b->P * b->nw);
+    for (size_t t = 0; t < total; t++) snapshot_body(b->state.data(), b->gstate.data(), b->N, t, idx, b->P, (uint32_t*)blob, 1, b->nw);
     return TETRIS_OK;
 }
 int tetris_set_dead(tetris_batch* b, const int32_t* idx, int n, const uint8_t* dead) {

@@ -12,14 +12,14 @@ from oracle import oracle as orc
 ENGINE_PARAMS = ["harness", pytest.param("hip", marks=pytest.mark.gpu)]
 
 
-def make(kind, n_games, n_players, height=20, pieces=(0, 1, 2, 3, 4, 5, 6), seeds=None):
+def make(kind, n_games, n_players, height=20, pieces=(0, 1, 2, 3, 4, 5, 6), seeds=None, colours=False):
     if kind == "oracle":
         return orc.OracleBatch(n_games, n_players, height, 10, pieces=pieces, seeds=seeds)
     pkg = ge.package()
     if kind == "harness":
-        return pkg.TetrisBatch(n_games, n_players, height, 10, pieces=pieces, seeds=seeds, lib_path=ge.build_harness())
+        return pkg.TetrisBatch(n_games, n_players, height, 10, pieces=pieces, seeds=seeds, lib_path=ge.build_harness(), colours=colours)
     if kind == "hip":
-        return pkg.TetrisBatch(n_games, n_players, height, 10, pieces=pieces, seeds=seeds, device=0)
+        return pkg.TetrisBatch(n_games, n_players, height, 10, pieces=pieces, seeds=seeds, device=0, colours=colours)
     raise ValueError(kind)
 
 

@@ -19,3 +19,18 @@ def test_engine_replays_reference_trace(kind, name):
 
     n = replay.replay(trace, factory, fields=FIELDS, occupancy_only=True, max_events=max_events, check_actions=True)
     assert n > 0
+
+
+@pytest.mark.parametrize("kind", engines.ENGINE_PARAMS)
+@pytest.mark.parametrize("name", ["greedy_2p", "keys_2p_22", "greedy_2p_o", "rt_2p"])
+def test_colour_planes_give_the_reference_field_values(kind, name):
+    """TETRIS_FLAG_COLOURS: State.field with tile values 1..7 / garbage 8 and GameplayData.garbageCleared exactly as the
+    compiled reference shows them (gamePlay.cpp:146,202; gameField.cpp:120-145), over traces with garbage traffic."""
+    trace = replay.load_trace(name)
+
+    def factory(P, H, W, pieces, seed):
+        return engines.make(kind, 1, P, H, pieces, seeds=seed, colours=True)
+
+    n = replay.replay(trace, factory, fields=FIELDS + replay.COLOUR_ONLY, occupancy_only=False,
+                      max_events=None if kind == "harness" else 1200)
+    assert n > 0

@@ -263,3 +263,40 @@ def test_observe_packed_matches_state_dict(kind, P, H):
             want[np.arange(len(sel)), 5 + r["next"]] = 1
             assert np.array_equal(vector[sl], want)
             assert np.array_equal(piece[sl], r["piece"])
+
+
+@pytest.mark.parametrize("kind", engines.ENGINE_PARAMS)
+def test_colour_batch_matches_oracle_cells(kind):
+    """Colour-tracking batches (TETRIS_FLAG_COLOURS) against the oracle's cell values on a garbage-heavy 2-player batch
+    (O pieces filling column pairs), incl. snapshot/restore of the wider state and the garbageCleared statistic."""
+    n, P = (2048 if kind == "hip" else 128), 2
+    seeds = orc.episode_seed(np.arange(n), 0)
+    eng = engines.make(kind, n, P, 20, pieces=(6, 4), seeds=seeds, colours=True)
+    ref = engines.make("oracle", n, P, 20, pieces=(6, 4), seeds=seeds)
+    rng = np.random.default_rng(4)
+    episode = np.zeros(n, np.int64)
+    blob = None
+    for s in range(220):
+        k = (s // 2 + np.arange(n)) % 5
+        trans = np.where(rng.random(n) < 0.05, rng.integers(0, 10, n), 2 * k).astype(np.uint8)
+        rot = (rng.random(n) < 0.1).astype(np.uint8)
+        d1 = eng.step_rt(rot, trans, s % 2)
+        d2 = ref.step_rt(rot, trans, s % 2)
+        assert np.array_equal(d1, d2)
+        if s % 20 == 19:
+            a, b = eng.observe()[0], ref.observe()[0]
+            assert np.array_equal(a["field"], b["field"]), s            # exact cell values 0..8
+            assert np.array_equal(a["garbage_cleared"], b["garbage_cleared"])
+        if s == 100:
+            blob = eng.snapshot()
+            assert blob.shape[1] == 4 + P * 68
+        idx = np.nonzero(d2)[0].astype(np.int32)
+        if len(idx):
+            episode[idx] += 1
+            eng.reset(idx, orc.episode_seed(idx, episode[idx]))
+            ref.reset(idx, orc.episode_seed(idx, episode[idx]))
+    rec = ref.observe()[0]
+    assert (rec["field"] == 8).any() and rec["garbage_cleared"].max() > 0
+    engines.assert_same_state(eng, ref, where="end")
+    eng.restore(blob)
+    assert np.array_equal(eng.snapshot(), blob)
