@@ -69,7 +69,7 @@ _SIGNATURES = {
     "tetris_observe_packed_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "tetris_create_split": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "tetris_split_stage_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "tetris_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "tetris_set_stream": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "tetris_rollout_random": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_uint32, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p]),
     "tetris_device_state": (C.c_void_p, [C.c_void_p]),
     "tetris_stream": (C.c_void_p, [C.c_void_p]),
@@ -273,8 +273,9 @@ class TetrisBatch:
         """One stage of a split-mode step; every argument is a raw device address (int) or None."""
         self._check(self.lib.tetris_split_stage_dev(self._h, int(stage), rot, trans, acting, int(ms), words, out, done, lines, dead))
 
-    def set_stream(self, stream_ptr):
-        self._check(self.lib.tetris_set_stream(self._h, stream_ptr))
+    def set_stream(self, stream_ptr, external=True):
+        """Run on a caller-owned HIP stream (handle as int; 0 = the legacy default stream).  external=False: own stream."""
+        self._check(self.lib.tetris_set_stream(self._h, C.c_void_p(int(stream_ptr) if stream_ptr else 0), 1 if external else 0))
 
     def set_game_offset(self, first_game_id):
         self._check(self.lib.tetris_set_game_offset(self._h, int(first_game_id)))

@@ -91,7 +91,7 @@ constexpr ShapeTable SHAPES = make_shape_table();
 struct Ctx {
     const uint32_t* shapes;          // 32 shape words (LDS on the GPU)
     const uint8_t* table;            // RNG table, one allocation: table[(chunk * 65536 + seed16) * 624 + r]
-    const uint32_t* start;           // [65536] first_ok | piece(j) << 8 | piece(j+1) << 16 (tetris_tables.h)
+    const uint64_t* start;           // [65536] first_ok | piece(j) << 8 | piece(j+1) << 16 | group(j+2) << 32 (tetris_tables.h)
     const double* combo_pow;         // [256] pow(c, 1.4 + 0.01 c) from the host libm (Combo.cpp:41)
     uint32_t n_draws;                // draws available per seed = n_chunks * 624
     uint32_t margin;                 // ST_NEED_EXTEND when a draw counter comes this close to n_draws
@@ -101,6 +101,7 @@ struct Ctx {
 };
 
 // ---------------------------------------------------------------- one player-board in registers
+struct Raw8 { uint32_t lo, hi; };   // 8 raw RNG-table bytes
 struct Player {
     uint32_t col[NCOL];
     uint32_t tint[3][NCOL];          // colour planes (only touched when Ctx::tint)
@@ -112,16 +113,17 @@ struct Player {
     uint32_t combo_remaining;
     float incoming;
     uint32_t piece_draws, hole_draws;
+    uint32_t pgroup;                 // dealt pieces of the aligned group of 8 draws holding draw `piece_draws`, nibble each
     uint32_t lines_sent, lines_cleared, lines_blocked, max_combo, lines_seen, garbage_cleared;
     int32_t qcount[FIFO_CAP];
     int32_t qdelay[FIFO_CAP];
     int q_loaded;                    // FIFO words were read from memory (qlen > 0 at load time)
-    uint32_t pf_next;                // prefetched table byte of draw `piece_draws` (valid while pf_ok)
+    Raw8 pf_raw;                     // prefetched raw table bytes of the group that starts at draw piece_draws + 1 (valid while pf_ok)
     int pf_ok;
 };
 
 // table bytes a reset will need, fetched ahead of time (see prefetch_reset)
-struct ResetPrefetch { uint32_t seed16, word; int ok; };
+struct ResetPrefetch { uint32_t seed16; uint64_t word; int ok; };
 
 template <int P>
 struct Game {
@@ -174,11 +176,12 @@ TE_HD void load_game(const uint32_t* state, const uint32_t* gstate, size_t n, si
         q.min_remaining = (int32_t)ld_stream(&s[(size_t)W_MIN_REMAINING * ws]);
         q.piece_draws = ld_stream(&s[(size_t)W_PIECE_DRAWS * ws]);
         q.hole_draws = ld_stream(&s[(size_t)W_HOLE_DRAWS * ws]);
+        q.pgroup = ld_stream(&s[(size_t)W_PIECE_GROUP * ws]);
         w = ld_stream(&s[(size_t)W_STATS0 * ws]); q.lines_sent = w & 0xFFFF; q.lines_cleared = w >> 16;
         w = ld_stream(&s[(size_t)W_STATS1 * ws]); q.lines_blocked = w & 0xFFFF; q.max_combo = w >> 16;
         w = ld_stream(&s[(size_t)W_STATS2 * ws]); q.lines_seen = w & 0xFFFF; q.garbage_cleared = w >> 16;
         q.q_loaded = q.qlen > 0;
-        q.pf_ok = 0; q.pf_next = 0;
+        q.pf_ok = 0; q.pf_raw.lo = 0; q.pf_raw.hi = 0;
         for (int i = 0; i < FIFO_CAP; i++) { q.qcount[i] = 0; q.qdelay[i] = 0; }
         if (q.q_loaded) {
             for (int i = 0; i < FIFO_CAP / 2; i++) {
@@ -222,6 +225,7 @@ TE_HD void store_game(uint32_t* state, uint32_t* gstate, size_t n, size_t slot, 
         st_stream(&s[(size_t)W_MIN_REMAINING * ws], (uint32_t)q.min_remaining);
         st_stream(&s[(size_t)W_PIECE_DRAWS * ws], q.piece_draws);
         st_stream(&s[(size_t)W_HOLE_DRAWS * ws], q.hole_draws);
+        st_stream(&s[(size_t)W_PIECE_GROUP * ws], q.pgroup);
         st_stream(&s[(size_t)W_STATS0 * ws], (q.lines_sent & 0xFFFF) | (q.lines_cleared << 16));
         st_stream(&s[(size_t)W_STATS1 * ws], (q.lines_blocked & 0xFFFF) | (q.max_combo << 16));
         st_stream(&s[(size_t)W_STATS2 * ws], (q.lines_seen & 0xFFFF) | (q.garbage_cleared << 16));
@@ -337,11 +341,42 @@ TE_HD uint32_t table_byte(const Ctx& cx, uint32_t seed16, uint32_t draw, uint32_
     return cx.table[((size_t)chunk * 65536u + seed16) * CHUNK + r];
 }
 
-// Issue the read of the next dealt piece early (right after the state load) so that its latency
-// hides under the key interpreter instead of sitting in front of the spawn test.
+// raw 8 table bytes of the aligned group of draws that holds `draw` (draw % 8 == 0 expected).  Loading and packing
+// are separate on purpose: a prefetch must not touch the loaded registers, or the wave waits for the load on the spot.
+TE_HD Raw8 table_group_raw(const Ctx& cx, uint32_t seed16, uint32_t draw, uint32_t& status) {
+    if (draw + 8u + cx.margin >= cx.n_draws) {
+        status |= ST_NEED_EXTEND;
+        if (draw + 8u > cx.n_draws) { status |= ST_STREAM_EXHAUSTED; draw = cx.n_draws - 8u; }
+    }
+    uint32_t chunk = draw / (uint32_t)CHUNK;
+    uint32_t r = draw - chunk * (uint32_t)CHUNK;                      // multiple of 8; 624 = 8 * 78: never straddles
+    const uint8_t* p = cx.table + ((size_t)chunk * 65536u + seed16) * CHUNK + r;
+    Raw8 v;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint2 w = *reinterpret_cast<const uint2*>(p);               // 8-byte aligned
+    v.lo = w.x; v.hi = w.y;
+#else
+    v.lo = 0; v.hi = 0;
+    for (int k = 0; k < 4; k++) { v.lo |= (uint32_t)p[k] << (8 * k); v.hi |= (uint32_t)p[4 + k] << (8 * k); }
+#endif
+    return v;
+}
+// the 8 low nibbles (dealt pieces) of 8 table bytes -> one word, nibble k = piece of draw 8g + k
+TE_HD uint32_t pack_group(Raw8 v) {
+    const uint32_t a = v.lo & 0x0F0F0F0Fu, b = v.hi & 0x0F0F0F0Fu;
+    uint32_t lo = (a | (a >> 4)) & 0x00FF00FFu; lo = (lo | (lo >> 8)) & 0x0000FFFFu;
+    uint32_t hi = (b | (b >> 4)) & 0x00FF00FFu; hi = (hi | (hi >> 8)) & 0x0000FFFFu;
+    return lo | (hi << 16);
+}
+
+// A spawn that consumes the LAST piece of the current group needs the next group afterwards: issue that read at the
+// top of the step (only 1 lane in 8 per step does), so its latency hides under the key interpreter.
 TE_HD void prefetch_next(const Ctx& cx, Player& q, uint32_t seed16, uint32_t& status) {
-    q.pf_next = table_byte(cx, seed16, q.piece_draws, status);
-    q.pf_ok = 1;
+    q.pf_ok = 0;
+    if ((q.piece_draws & 7u) == 7u) {
+        q.pf_raw = table_group_raw(cx, seed16, q.piece_draws + 1u, status);
+        q.pf_ok = 1;
+    }
 }
 
 // ---------------------------------------------------------------- garbage queue (Garbage.cpp)
@@ -445,10 +480,16 @@ TE_HD bool spawn_next(const Ctx& cx, Player& q, uint32_t seed16, uint32_t& statu
     q.rot = spawn_rot(q.kind);
     q.x = (NCOL - 4) / 2;
     q.y = 0;
-    uint32_t byte = q.pf_ok ? q.pf_next : table_byte(cx, seed16, q.piece_draws, status);
-    q.pf_ok = 0;
-    q.next = (int)(byte & 7u);
+    if (q.piece_draws + cx.margin >= cx.n_draws) {
+        status |= ST_NEED_EXTEND;
+        if (q.piece_draws >= cx.n_draws) status |= ST_STREAM_EXHAUSTED;
+    }
+    q.next = (int)((q.pgroup >> (4u * (q.piece_draws & 7u))) & 7u);
     q.piece_draws++;
+    if ((q.piece_draws & 7u) == 0u) {                       // crossed into the next aligned group of 8 draws
+        q.pgroup = pack_group(q.pf_ok ? q.pf_raw : table_group_raw(cx, seed16, q.piece_draws, status));
+        q.pf_ok = 0;
+    }
     uint32_t shape = shape_of(cx, q.kind, q.rot);
     if (!fits_at(cx, q, shape, q.x, 0)) { stamp(cx, q, shape); return true; }
     return false;
@@ -565,8 +606,9 @@ TE_HD void restart_player(const Ctx& cx, Player& q, uint32_t seed16, uint32_t& s
     q.speedup_time = 0; q.drop_delay = 1000; q.drop_time = 0; q.lock_time = 0; q.lock_armed = 0;
     q.time_ms = 0; q.incoming = 0.0f; q.lines_seen = 0; q.dead = 0;
     (void)status;
-    const uint32_t word = (pf && pf->ok && pf->seed16 == seed16) ? pf->word : cx.start[seed16];
-    const uint32_t j = word & 0xFFu, b0 = (word >> 8) & 0xFFu, b1 = (word >> 16) & 0xFFu;
+    const uint64_t word = (pf && pf->ok && pf->seed16 == seed16) ? pf->word : cx.start[seed16];
+    const uint32_t j = (uint32_t)word & 0xFFu, b0 = ((uint32_t)word >> 8) & 0xFFu, b1 = ((uint32_t)word >> 16) & 0xFFu;
+    q.pgroup = (uint32_t)(word >> 32);
     q.kind = (int)(b0 & 7u);
     q.next = (int)(b1 & 7u);
     q.pf_ok = 0;

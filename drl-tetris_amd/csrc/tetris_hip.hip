@@ -71,11 +71,11 @@ __global__ __launch_bounds__(256) void k_gen_seed(uint32_t* mt) {
 
 struct MapArg { uint8_t m[8]; };
 
-__global__ __launch_bounds__(256) void k_gen_chunk(uint32_t* mt, float* w, uint8_t* out, uint32_t* start, int chunk,
+__global__ __launch_bounds__(256) void k_gen_chunk(uint32_t* mt, float* w, uint8_t* out, uint64_t* start, int chunk,
                                                    MapArg map, int only_sz) {
     uint32_t seed = blockIdx.x * blockDim.x + threadIdx.x;
     if (seed >= 65536u) return;
-    uint32_t word = 0;
+    uint64_t word = 0;
     gen_chunk_for_seed(mt + seed, 65536, w + seed, 65536, out + (size_t)seed * CHUNK, &word, chunk, map.m, only_sz != 0);
     if (chunk == 0) start[seed] = word;
 }
@@ -176,7 +176,7 @@ struct Tables {
     int refs = 0;
     uint32_t* d_mt = nullptr;        // [624][65536]
     float* d_w = nullptr;            // [7][65536]
-    uint32_t* d_start = nullptr;     // [65536] per-seed start words
+    uint64_t* d_start = nullptr;     // [65536] per-seed start entries
     double* d_pow = nullptr;         // [256]
     uint8_t* d_table = nullptr;      // [(chunk * 65536 + seed) * 624 + r], capacity `cap_chunks`
     int n_chunks = 0, cap_chunks = 0;
@@ -220,7 +220,7 @@ static int tables_acquire(Tables** out, int device, const uint8_t map[7], hipStr
     for (int i = 0; i < 7; i++) if (map[i] != 2 && map[i] != 3) t->only_sz = 0;
     HIP_TRY(hipMalloc((void**)&t->d_mt, (size_t)624 * 65536 * 4));
     HIP_TRY(hipMalloc((void**)&t->d_w, (size_t)7 * 65536 * 4));
-    HIP_TRY(hipMalloc((void**)&t->d_start, 65536 * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void**)&t->d_start, 65536 * sizeof(uint64_t)));
     HIP_TRY(hipMalloc((void**)&t->d_pow, 256 * sizeof(double)));
     double powtab[256];
     for (int c = 0; c < 256; c++) powtab[c] = pow((double)c, 1.4 + (double)c * 0.01);   // Combo.cpp:41, host libm
@@ -483,11 +483,11 @@ int tetris_create_split(tetris_batch** out, int n_games, int side, int height, i
     return create_impl(out, n_games, 1, height, width, piece_map, device, seeds, 1, side);
 }
 
-int tetris_set_stream(tetris_batch* b, void* hip_stream) {
+int tetris_set_stream(tetris_batch* b, void* hip_stream, int external) {
     int rc = check_batch(b);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(b->stream));
-    b->stream = hip_stream ? (hipStream_t)hip_stream : b->own_stream;
+    b->stream = external ? (hipStream_t)hip_stream : b->own_stream;      // NULL + external = the legacy default stream
     return TETRIS_OK;
 }
 

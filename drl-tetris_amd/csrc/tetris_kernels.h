@@ -15,7 +15,7 @@ struct KArgs {
     uint32_t* gstate;
     uint32_t* status;
     const uint8_t* table;     // [(chunk * 65536 + seed16) * 624 + r]
-    const uint32_t* start;    // [65536] per-seed start words
+    const uint64_t* start;    // [65536] per-seed start entries
     const double* combo_pow;
     uint32_t n_draws, margin;
     int H;

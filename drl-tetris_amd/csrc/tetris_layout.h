@@ -40,14 +40,15 @@ enum Word : int {
     W_STATS0 = 23,         // linesSent[0:16) | linesCleared[16:32)
     W_STATS1 = 24,         // linesBlocked[0:16) | maxCombo[16:32)
     W_STATS2 = 25,         // GamePlay.linesCleared ("seen")[0:16) | garbageCleared[16:32)
-    W_FIFO_COUNT0 = 26,    // 4 words: Garbage.count, two int16 per word
-    W_FIFO_DELAY0 = 30,    // 8 words: Garbage.delay
-    NWORDS = 38,
-    NWORDS_HOT = 26,       // words touched by every step; the FIFO words only when a queue exists
+    W_PIECE_GROUP = 26,    // dealt pieces of draws 8*(piece_draws/8) .. +7, one nibble each (cache of the RNG table)
+    W_FIFO_COUNT0 = 27,    // 4 words: Garbage.count, two int16 per word
+    W_FIFO_DELAY0 = 31,    // 8 words: Garbage.delay
+    NWORDS = 39,
+    NWORDS_HOT = 27,       // words touched by every step; the FIFO words only when a queue exists
     // optional colour planes (batches created with TETRIS_FLAG_COLOURS): plane k, column c at W_TINT0 + 10 k + c holds
     // bit k of (cell value - 1) for every occupied square: tiles 1..7 (gamePlay.cpp:146) and 8 = garbage (gamePlay.cpp:202)
-    W_TINT0 = 38,
-    NWORDS_TINT = 68
+    W_TINT0 = 39,
+    NWORDS_TINT = 69
 };
 
 enum GameWord : int {

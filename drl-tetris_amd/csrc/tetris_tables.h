@@ -10,9 +10,11 @@
 //    randomizer.cpp:10-32,55-62) => the *sequence of dealt pieces* is a pure function of the seed
 //    (and of the batch-wide piece map, PythonHandle.h:116-121).
 //  => table[seed][k] = piece dealt by draw k (low nibble) | hole chosen by draw k (high nibble),
-//     start[seed] = j | table(j) << 8 | table(j+1) << 16 with j = index of the first draw accepted by the
-//     S/Z redraw loop.  After a reset a board holds current = piece(j), next = piece(j+1),
-//     piece_draws = j+2, hole_draws = 0 — one 4-byte load.
+//     start[seed] (8 bytes) = j | table(j) << 8 | table(j+1) << 16 | pieces of the aligned group of 8 draws that
+//     holds draw j+2, with j = index of the first draw accepted by the S/Z redraw loop.  After a reset a board holds
+//     current = piece(j), next = piece(j+1), piece_draws = j+2, hole_draws = 0 — one 8-byte load.
+//  A board also carries the dealt pieces of its current aligned group of 8 draws in one state word
+//  (W_PIECE_GROUP), so it reads the table once per 8 pieces instead of pulling a 128-byte line per piece.
 //
 // std::mt19937 itself is libstdc++ (third party, not vendored in the reference): the published
 // MT19937 (Matsumoto & Nishimura 1998), init_genrand seeding; KAT in tests (seed 1000 ->
@@ -99,8 +101,15 @@ TE_HD int pick_hole(uint32_t draw) { return (int)(short)(unit_float(draw) * 10.0
 //   w       : 7 weights, strided; carried between chunks
 //   out     : 624 bytes of this seed's row in the chunk table
 //   first_ok: written when chunk == 0
+// low nibbles of the 8 table bytes of one aligned group of draws -> one word, nibble k = piece of draw 8g + k
+TE_HD uint32_t group_word(const uint8_t* bytes8) {
+    uint32_t w = 0;
+    for (int k = 0; k < 8; k++) w |= (uint32_t)(bytes8[k] & 0xFu) << (4 * k);
+    return w;
+}
+
 TE_HD void gen_chunk_for_seed(uint32_t* mt, size_t stride, float* w, size_t ws, uint8_t* out,
-                              uint32_t* start_word, int chunk, const uint8_t* map, bool only_sz) {
+                              uint64_t* start_word, int chunk, const uint8_t* map, bool only_sz) {
     uint8_t first_ok_store = 0;
     uint8_t* first_ok = &first_ok_store;
     mt_twist(mt, stride);
@@ -120,11 +129,13 @@ TE_HD void gen_chunk_for_seed(uint32_t* mt, size_t stride, float* w, size_t ws, 
         packed |= byte << (8 * (k & 3));
         if ((k & 3) == 3) { ((uint32_t*)out)[k >> 2] = packed; packed = 0; }
     }
-    // start word of this seed: everything a reset reads, in one 4-byte load:
-    //   first_ok j [0:8) | table byte of draw j [8:16) | table byte of draw j+1 [16:24)
+    // start entry of this seed: everything a reset reads, in one 8-byte load:
+    //   first_ok j [0:8) | table byte of draw j [8:16) | table byte of draw j+1 [16:24) | piece group of draw j+2 [32:64)
     if (chunk == 0) {
         uint32_t j = first_ok_store;
-        *start_word = j | ((uint32_t)out[j] << 8) | ((uint32_t)out[j + 1] << 16);
+        uint32_t lo = j | ((uint32_t)out[j] << 8) | ((uint32_t)out[j + 1] << 16);
+        uint32_t hi = group_word(out + ((j + 2) & ~7u));
+        *start_word = (uint64_t)lo | ((uint64_t)hi << 32);
     }
 }
 

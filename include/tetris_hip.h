@@ -187,8 +187,10 @@ int tetris_split_stage_dev(tetris_batch *b, int stage, const uint8_t *d_rot, con
                            const uint8_t *d_acting, int ms, const uint32_t *d_words, uint32_t *d_out,
                            uint8_t *d_done, uint8_t *d_lines, uint8_t *d_dead);
 /* Run the batch on a caller-owned HIP stream (e.g. torch's current stream) so that its kernels are ordered with the
- * caller's collectives without host synchronisation; NULL = back to the batch's own stream.                      */
-int tetris_set_stream(tetris_batch *b, void *hip_stream);
+ * caller's copies and collectives without host synchronisation.  external != 0: use `hip_stream` as given — NULL is
+ * then the legacy default stream, which is what torch.cuda.current_stream() usually is; external == 0: back to the
+ * batch's own stream (hip_stream ignored).                                                                        */
+int tetris_set_stream(tetris_batch *b, void *hip_stream, int external);
 
 /* plumbing for zero-copy callers (torch / another HIP library)                                   */
 void *tetris_device_state(tetris_batch *b);            /* uint32 [NWORDS][P][N]                  */

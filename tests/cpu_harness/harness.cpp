@@ -26,7 +26,7 @@ struct Tables {
     int only_sz = 0;
     std::vector<uint32_t> mt;        // [624][65536]
     std::vector<float> w;            // [7][65536]
-    std::vector<uint32_t> start;     // [65536] per-seed start words
+    std::vector<uint64_t> start;     // [65536] per-seed start entries
     double powtab[256];
     std::vector<uint8_t> table;      // [(chunk * 65536 + seed) * 624 + r]
     int n_chunks = 0;
@@ -36,7 +36,7 @@ struct Tables {
         uint8_t* out = table.data() + (size_t)65536 * CHUNK * c;
 #pragma omp parallel for schedule(static)
         for (int seed = 0; seed < 65536; seed++) {
-            uint32_t word = 0;
+            uint64_t word = 0;
             gen_chunk_for_seed(mt.data() + seed, 65536, w.data() + seed, 65536, out + (size_t)seed * CHUNK, &word, c, map, only_sz != 0);
             if (c == 0) start[seed] = word;
         }
@@ -194,7 +194,7 @@ int tetris_create_split(tetris_batch** out, int n_games, int side, int height, i
     if (side != 0 && side != 1) return fail(TETRIS_E_ARG, "side must be 0 or 1");
     return create_impl(out, n_games, 1, height, width, piece_map, seeds, 1, side);
 }
-int tetris_set_stream(tetris_batch*, void*) { return TETRIS_OK; }
+int tetris_set_stream(tetris_batch*, void*, int) { return TETRIS_OK; }
 int tetris_split_stage_dev(tetris_batch* b, int stage, const uint8_t* rot, const uint8_t* trans, const uint8_t* acting, int ms,
                            const uint32_t* words, uint32_t* outw, uint8_t* done, uint8_t* lines, uint8_t* dead) {
     if (!b->split) return fail(TETRIS_E_ARG, "not a split batch");

@@ -91,7 +91,11 @@ def test_split_kernels_on_gpu_match_colocated_oracle(scenario, pieces):
     rec, ro, lw = ref.observe()
     for side in (0, 1):
         (got, gro, glw), dones = results[side]
-        assert np.array_equal(dones, np.stack(want)), side
+        w = np.stack(want)
+        if not np.array_equal(dones, w):
+            st, gm = np.argwhere(dones != w)[0]
+            raise AssertionError(f"side {side}: done differs first at step {st}, game {gm}: got {dones[st, gm]} want {w[st, gm]}; "
+                                 f"{int((dones != w).sum())} differences in total")
         for f in FIELDS:
             assert np.array_equal(got[f][:, 0], rec[f][:, side]), (side, f)
         assert np.array_equal(got["field"][:, 0] > 0, rec["field"][:, side] > 0)
