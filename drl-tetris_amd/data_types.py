@@ -25,38 +25,36 @@ null_action = action([0])
 
 
 class action_list:
-    """Ordered, de-duplicated list of actions with the reference's null-move policy
-    (data_types/action_list.py:3-37): the null action is put first unless already present; with
-    remove_null it is dropped again while other actions remain."""
+    """Ordered set of actions with the reference's null-move policy (data_types/action_list.py:3-37):
+    duplicates are dropped keeping first occurrences; unless the input already contains the null action it is put in
+    front; `remove_null` then strips every null action again as long as something else remains."""
 
     def __init__(self, container=None, remove_null=False):
         self.remove_null = remove_null
-        if container is None or len(container) == 0:
-            container = [null_action]
-        self.container = [] if null_action in container else [null_action]
-        for x in container:
-            assert type(x) in (action, list), f"attempted to create action list with non-list type actions (x={x} type(x)={type(x)})."
-            if x not in self.container:
-                self.container.append(action(x))
-        if self.remove_null:
+        source = list(container) if container is not None and len(container) > 0 else [null_action]
+        for item in source:
+            assert type(item) in (action, list), (
+                f"attempted to create action list with non-list type actions (x={item} type(x)={type(item)}).")
+        ordered = ([] if null_action in source else [null_action]) + [action(item) for item in source]
+        self.container = []
+        for item in ordered:
+            if item not in self.container:
+                self.container.append(item)
+        if remove_null:
             self.remove_nulls()
 
     def remove_nulls(self):
-        while len(self.container) > 1 and null_action in self.container:
-            self.container.remove(null_action)
+        others = [a for a in self.container if a != null_action]
+        if others:
+            self.container = others
+        else:
+            self.container = self.container[:1]
 
-    def __add__(self, n):
-        return action_list(n.container + self.container, remove_null=(n.remove_null and self.remove_null))
-
-    def __str__(self):
-        return "action_list(" + str(self.container) + ")"
-
-    __repr__ = __str__
+    def __add__(self, other):
+        return action_list(other.container + self.container, remove_null=(other.remove_null and self.remove_null))
 
     def __getitem__(self, key):
-        if key > len(self.container):
-            return null_action
-        return self.container[key]
+        return null_action if key > len(self.container) else self.container[key]       # sic: action_list.py:27-32
 
     def __len__(self):
         return len(self.container)
@@ -67,72 +65,81 @@ class action_list:
     def __contains__(self, x):
         return x in self.container
 
+    def __repr__(self):
+        return f"action_list({self.container})"
+
+    __str__ = __repr__
+
+
+def _vec(x):
+    return np.array(x).ravel()
+
 
 class reward:
-    """Vector-valued reward with extrinsic/intrinsic parts (reference: data_types/reward.py:7-52)."""
+    """Vector-valued reward split into an extrinsic and an intrinsic part; behaves like the reference's
+    data_types/reward.py:7-52: `r()` is the sum of both parts, `+`/`-` combine part-wise through the subclass rules,
+    the positional form is reward(extrinsic) (a second positional value is accepted and ignored there too)."""
 
     def __init__(self, *args, **kwargs):
         if len(args) > 2:
             raise ValueError("reward needs to have 0, 1 or 2 arguments: [<extrinsic>] [<intrinsic>]")
-        if len(args) > 0:
-            if "extrinsic" in kwargs:
-                raise ValueError("Doubly specified extrinsic :(")
-            self._extrinsic = np.array(args[0]).ravel()
-        else:
-            self._extrinsic = np.array(kwargs.pop("extrinsic")).ravel()
-        # (the reference never reads a positional intrinsic: reward.py:14-21)
-        self._intrinsic = np.array(kwargs.pop("intrinsic", np.zeros((1,)))).ravel()
+        if args and "extrinsic" in kwargs:
+            raise ValueError("Doubly specified extrinsic :(")
+        self._extrinsic = _vec(args[0] if args else kwargs.pop("extrinsic"))
+        self._intrinsic = _vec(kwargs.pop("intrinsic", np.zeros((1,))))
+
+    extrinsic = property(lambda self: self._extrinsic)
+    intrinsic = property(lambda self: self._intrinsic)
+    reward = property(lambda self: self._extrinsic)
 
     def ext_rule(self, *args, **kwargs):
         raise ValueError("Dont use base-class!")
 
-    int_rule = ext_rule
+    def int_rule(self, *args, **kwargs):
+        raise ValueError("Dont use base-class!")
 
-    @property
-    def reward(self):
-        return self._extrinsic
+    def _combine(self, other, **mode):
+        return type(self)(extrinsic=self.ext_rule(self._extrinsic, other._extrinsic, **mode),
+                          intrinsic=self.int_rule(self._intrinsic, other._intrinsic, **mode))
 
-    @property
-    def extrinsic(self):
-        return self._extrinsic
+    def __add__(self, other):
+        return self._combine(other, add=True)
 
-    @property
-    def intrinsic(self):
-        return self._intrinsic
+    def __sub__(self, other):
+        return self._combine(other, sub=True)
 
     def __call__(self, separate_components=False):
         if separate_components:
-            return (self._extrinsic, self._extrinsic)       # sic: reward.py:42
+            return (self._extrinsic, self._extrinsic)       # sic: reward.py:42 returns the extrinsic part twice
         return self._extrinsic.sum() + self._intrinsic.sum()
 
-    def __add__(self, other):
-        return type(self)(extrinsic=self.ext_rule(self._extrinsic, other._extrinsic, add=True),
-                          intrinsic=self.int_rule(self._intrinsic, other._intrinsic, add=True))
+    def __repr__(self):
+        return f"reward<R={self()}=({self._extrinsic.tolist()}, {self._intrinsic.tolist()} )>"
 
-    def __sub__(self, other):
-        return type(self)(extrinsic=self.ext_rule(self._extrinsic, other._extrinsic, sub=True),
-                          intrinsic=self.int_rule(self._intrinsic, other._intrinsic, sub=True))
-
-    def __str__(self):
-        return "reward<R=" + str(self()) + "=(" + str(self.extrinsic.tolist()) + ", " + str(self.intrinsic.tolist()) + " )>"
-
-    __repr__ = __str__
+    __str__ = __repr__
 
 
 class standard_reward(reward):
-    def ext_rule(self, x, y, add=False, sub=False):
+    """Plain element-wise combination of both parts (reward.py:55-62)."""
+
+    @staticmethod
+    def _elementwise(x, y, add=False, sub=False):
         return x + y if add else x - y
 
-    int_rule = ext_rule
+    def ext_rule(self, x, y, **mode):
+        return self._elementwise(x, y, **mode)
+
+    def int_rule(self, x, y, **mode):
+        return self._elementwise(x, y, **mode)
 
 
 class maingoal_reward(standard_reward):
-    """Only component 0 of the other operand's extrinsic part is combined (reward.py:64-71)."""
+    """Of the other operand's extrinsic part only component 0 (the win/lose signal) takes part (reward.py:64-71)."""
 
-    def ext_rule(self, x, y, add=False, sub=False):
-        tmp = np.zeros_like(y)
-        tmp[0] = y[0]
-        return x + tmp if add else x - tmp
+    def ext_rule(self, x, y, **mode):
+        main_only = np.zeros_like(y)
+        main_only[0] = y[0]
+        return self._elementwise(x, main_only, **mode)
 
 
 class coopintrinsic_reward(maingoal_reward):
@@ -185,42 +192,43 @@ class backend_snapshot:
 
 
 class state:
-    """Reference: data_types/state.py:1-40 — a snapshot of one game plus a lazy per-player processor."""
+    """A snapshot of one game plus a lazy per-player processor — same surface as the reference's data_types/state.py:1-40
+    (`backend_state`, `is_dead`, `lock`/`unlock`, indexing by player, iteration over the raw per-player views)."""
 
     def __init__(self, backend_state, state_processor, unlocked=True):
-        self.unlocked = unlocked
         self.state_processor = state_processor
         self.backend_state = backend_state.copy()
-        self.is_dead = [x.dead[0] for x in backend_state.states]
+        self.is_dead = [view.dead[0] for view in backend_state.states]
+        self.unlocked = True
         if not unlocked:
             self.lock()
 
+    def _write_dead(self, values):
+        for view, value in zip(self.backend_state.states, values):
+            view.dead[0] = value
+
     def lock(self):
-        for s in self.backend_state.states:
-            s.dead[0] = 1            # prevents the state from being changed by performing actions
+        """Marks every player dead in the snapshot, so that actions performed on it change nothing (state.py:9-12)."""
+        self._write_dead([1] * len(self))
         self.unlocked = False
 
     def unlock(self):
-        for i, s in enumerate(self.backend_state.states):
-            s.dead[0] = self.is_dead[i]
+        self._write_dead(self.is_dead)
         self.unlocked = True
 
-    def __getitem__(self, idx):
+    def _players(self, idx):
         if isinstance(idx, slice):
-            return [self.state_processor(self.backend_state, x) for x in range(*idx.indices(len(self.backend_state.states)))]
-        if not hasattr(idx, "__iter__"):
+            return list(range(*idx.indices(len(self))))
+        return list(idx) if hasattr(idx, "__iter__") else None
+
+    def __getitem__(self, idx):
+        players = self._players(idx)
+        if players is None:
             return self.state_processor(self.backend_state, idx)
-        return [self.state_processor(self.backend_state, i) for i in idx]
+        return [self.state_processor(self.backend_state, p) for p in players]
 
     def __len__(self):
         return len(self.backend_state.states)
 
     def __iter__(self):
-        self.current = -1
-        return self
-
-    def __next__(self):
-        self.current += 1
-        if self.current == len(self.backend_state.states):
-            raise StopIteration
-        return self.backend_state.states[self.current]
+        return iter(self.backend_state.states)
