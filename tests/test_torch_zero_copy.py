@@ -1,0 +1,48 @@
+"""The device-pointer entry points (tetris_step_rt_dev, tetris_observe_packed_dev) driven from torch tensors on the batch's
+GPU, on torch's stream: an agent-shaped loop (observe -> choose action on device -> step) without any host copy, checked
+against the oracle."""
+import numpy as np
+import pytest
+
+import __graft_entry__ as ge
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def test_zero_copy_loop_matches_oracle():
+    import importlib
+
+    import torch
+    pkg = ge.package()
+    interop = importlib.import_module("drl-tetris_amd.torch_interop")
+    n, P, H = 4096, 2, 20
+    seeds = orc.episode_seed(np.arange(n), 0)
+    batch = pkg.TetrisBatch(n, P, H, 10, seeds=seeds, device=0)
+    ref = orc.OracleBatch(n, P, H, 10, seeds=seeds)
+    env = interop.TorchEnv(batch)
+    gen = torch.Generator(device="cuda").manual_seed(7)
+    for s in range(48):
+        me = torch.full((n,), s % 2, dtype=torch.uint8, device="cuda")
+        visual, vector, piece = env.observe(me)
+        # a "policy" computed on the device from the observation: column of the lowest stack + noise, rotation from the piece id
+        heights = visual[0].to(torch.int32).flip(1).cumsum(1).gt(0).sum(1)            # [n, W] stack heights of my board
+        trans = (heights.argmin(1) + torch.randint(0, 2, (n,), generator=gen, device="cuda")).clamp(0, 9).to(torch.uint8)
+        rot = (piece[0] % 4).to(torch.uint8)
+        done, lines, dead = env.step_rt(rot, trans, me)
+        d_ref = ref.step_rt(rot.cpu().numpy(), trans.cpu().numpy(), me.cpu().numpy())
+        assert np.array_equal(done.cpu().numpy(), d_ref), s
+        rec = ref.observe()[0]
+        assert np.array_equal(dead.cpu().numpy().T, rec["dead"]) and np.array_equal(lines.cpu().numpy().T, rec["reward"])
+        idx = np.nonzero(d_ref)[0].astype(np.int32)
+        if len(idx):
+            torch.cuda.synchronize()
+            sd = orc.episode_seed(idx, s + 1)
+            batch.reset(idx, sd)
+            ref.reset(idx, sd)
+    visual, vector, piece = env.observe(torch.zeros(n, dtype=torch.uint8, device="cuda"))
+    rec = ref.observe()[0]
+    assert np.array_equal(visual[0].cpu().numpy(), (rec["field"][:, 0, :H] > 0).astype(np.uint8))
+    assert np.array_equal(visual[1].cpu().numpy(), (rec["field"][:, 1, :H] > 0).astype(np.uint8))
+    assert np.array_equal(piece[0].cpu().numpy(), rec["piece"][:, 0])
+    batch.close()
