@@ -78,10 +78,35 @@ _SIGNATURES = {
 EXPORTS = tuple(_SIGNATURES)
 
 
+def _share_hip_runtime_with_torch():
+    """One process must use ONE HIP runtime.  PyTorch-ROCm wheels bundle their own libamdhip64; if this library pulled
+    in the system copy first, a later `import torch` would load a second runtime and find no GPU.  So when torch is
+    installed (not necessarily imported), load its bundled runtime first with RTLD_GLOBAL; libtetris_hip.so's
+    libamdhip64 dependency then resolves to it.  Without torch the system ROCm runtime is used."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return                              # torch already loaded its runtime
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    for root in (spec.submodule_search_locations if spec and spec.submodule_search_locations else []):
+        cand = os.path.join(root, "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            try:
+                C.CDLL(cand, mode=C.RTLD_GLOBAL)
+            except OSError:
+                pass
+            return
+
+
 def load_library(lib_path=None):
     path = os.path.abspath(lib_path or DEFAULT_LIB)
     if path in _libs:
         return _libs[path]
+    if lib_path is None:
+        _share_hip_runtime_with_torch()
     if not os.path.exists(path):
         raise TetrisError(f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
