@@ -208,6 +208,15 @@ static int tables_extend(Tables* t, hipStream_t stream) {
     return TETRIS_OK;
 }
 
+static void tables_free(Tables* t) {
+    (void)hipFree(t->d_mt); (void)hipFree(t->d_w); (void)hipFree(t->d_start); (void)hipFree(t->d_pow);
+    (void)hipFree(t->d_table);
+    for (uint8_t* c : t->retired) (void)hipFree(c);
+    delete t;
+}
+
+static int tables_build(Tables* t, hipStream_t stream);
+
 static int tables_acquire(Tables** out, int device, const uint8_t map[7], hipStream_t stream) {
     std::lock_guard<std::mutex> lock(g_tab_mutex);
     for (Tables* t : g_tables)
@@ -218,6 +227,15 @@ static int tables_acquire(Tables** out, int device, const uint8_t map[7], hipStr
     memcpy(t->map, map, 7);
     t->only_sz = 1;                                             // PythonHandle.h:116-121 set_pieces
     for (int i = 0; i < 7; i++) if (map[i] != 2 && map[i] != 3) t->only_sz = 0;
+    int rc = tables_build(t, stream);
+    if (rc) { std::string keep = g_err; tables_free(t); return fail(rc, keep); }
+    t->refs = 1;
+    g_tables.push_back(t);
+    *out = t;
+    return TETRIS_OK;
+}
+
+static int tables_build(Tables* t, hipStream_t stream) {
     HIP_TRY(hipMalloc((void**)&t->d_mt, (size_t)624 * 65536 * 4));
     HIP_TRY(hipMalloc((void**)&t->d_w, (size_t)7 * 65536 * 4));
     HIP_TRY(hipMalloc((void**)&t->d_start, 65536 * sizeof(uint64_t)));
@@ -232,9 +250,6 @@ static int tables_acquire(Tables** out, int device, const uint8_t map[7], hipStr
         int rc = tables_extend(t, stream);
         if (rc) return rc;
     }
-    t->refs = 1;
-    g_tables.push_back(t);
-    *out = t;
     return TETRIS_OK;
 }
 
@@ -243,10 +258,7 @@ static void tables_release(Tables* t) {
     if (--t->refs > 0) return;
     for (size_t i = 0; i < g_tables.size(); i++)
         if (g_tables[i] == t) { g_tables.erase(g_tables.begin() + i); break; }
-    (void)hipFree(t->d_mt); (void)hipFree(t->d_w); (void)hipFree(t->d_start); (void)hipFree(t->d_pow);
-    (void)hipFree(t->d_table);
-    for (uint8_t* c : t->retired) (void)hipFree(c);
-    delete t;
+    tables_free(t);
 }
 
 // grow-on-demand device + pinned-host staging pair
@@ -288,15 +300,19 @@ struct tetris_batch {
     int tint = 0, nw = NWORDS;           // colour planes tracked; words per player-board
     uint32_t* d_shadow = nullptr;        // split mode, side 1
     hipStream_t own_stream = nullptr;
-    Stage s_idx, s_in0, s_in1, s_in2, s_out0, s_out1, s_out2, s_big;
+    Stage s_idx, s_in0, s_in1, s_in2, s_out0, s_out1, s_out2, s_big, s_act0, s_act1, s_act2;
 };
 
 static KArgs base_args(tetris_batch* b, int n, const int32_t* d_idx) {
     KArgs a;
     memset(&a, 0, sizeof a);
     a.state = b->d_state; a.gstate = b->d_gstate; a.status = b->d_status;
-    a.table = b->tab->d_table; a.start = b->tab->d_start; a.combo_pow = b->tab->d_pow;
-    a.n_draws = (uint32_t)b->tab->n_chunks * CHUNK; a.margin = b->margin;
+    {   // tables are shared between batches: take pointer and size together (another batch may be growing them)
+        std::lock_guard<std::mutex> lock(g_tab_mutex);
+        a.table = b->tab->d_table;
+        a.n_draws = (uint32_t)b->tab->n_chunks * CHUNK;
+    }
+    a.start = b->tab->d_start; a.combo_pow = b->tab->d_pow; a.margin = b->margin;
     a.H = b->H; a.n_games = b->N; a.n = n; a.idx = d_idx; a.game_offset = b->game_offset;
     return a;
 }
@@ -388,7 +404,7 @@ int tetris_destroy(tetris_batch* b) {
     if (b->tab) tables_release(b->tab);
     (void)hipFree(b->d_shadow); (void)hipFree(b->d_state); (void)hipFree(b->d_gstate); (void)hipFree(b->d_status); (void)hipFree(b->d_counters);
     if (b->h_status) (void)hipHostFree(b->h_status);
-    Stage* all[] = {&b->s_idx, &b->s_in0, &b->s_in1, &b->s_in2, &b->s_out0, &b->s_out1, &b->s_out2, &b->s_big};
+    Stage* all[] = {&b->s_idx, &b->s_in0, &b->s_in1, &b->s_in2, &b->s_out0, &b->s_out1, &b->s_out2, &b->s_big, &b->s_act0, &b->s_act1, &b->s_act2};
     for (Stage* s : all) s->release();
     if (b->ev0) (void)hipEventDestroy(b->ev0);
     if (b->ev1) (void)hipEventDestroy(b->ev1);
@@ -832,7 +848,7 @@ int tetris_get_actions(tetris_batch* b, const int32_t* idx, int n, const uint8_t
             if (player[i] >= b->P) return fail(TETRIS_E_ARG, "player index out of range");
     const int LANE_LISTS = 16;                       // lists one (x, rotation) start can produce (<= H/2)
     const int CHUNK_GAMES = 1024;                    // bounds the staging buffers
-    Stage s_cnt, s_len, s_key;
+    Stage &s_cnt = b->s_act0, &s_len = b->s_act1, &s_key = b->s_act2;
     int result = TETRIS_OK;
     for (int g0 = 0; g0 < n && result == TETRIS_OK; g0 += CHUNK_GAMES) {
         const int m = (n - g0 < CHUNK_GAMES) ? n - g0 : CHUNK_GAMES;
@@ -880,7 +896,6 @@ int tetris_get_actions(tetris_batch* b, const int32_t* idx, int n, const uint8_t
             count[g0 + i] = total;
         }
     }
-    s_cnt.release(); s_len.release(); s_key.release();
     return result;
 }
 
