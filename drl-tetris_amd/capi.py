@@ -64,6 +64,9 @@ _SIGNATURES = {
     "tetris_restore": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "tetris_set_dead": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "tetris_enumerate_drops": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "tetris_enumerate_drops_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "tetris_timer_start": (C.c_int, [C.c_void_p]),
+    "tetris_timer_stop": (C.c_int, [C.c_void_p, C.c_void_p]),
     "tetris_get_actions": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "tetris_observe_packed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "tetris_observe_packed_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -304,6 +307,14 @@ class TetrisBatch:
 
     def set_game_offset(self, first_game_id):
         self._check(self.lib.tetris_set_game_offset(self._h, int(first_game_id)))
+
+    def timer_start(self):
+        self._check(self.lib.tetris_timer_start(self._h))
+
+    def timer_stop(self):
+        ms = C.c_float(0.0)
+        self._check(self.lib.tetris_timer_stop(self._h, C.byref(ms)))
+        return float(ms.value)
 
     def sync(self):
         self._check(self.lib.tetris_sync(self._h))

@@ -837,6 +837,42 @@ int tetris_enumerate_drops(tetris_batch* b, const int32_t* idx, int n, const uin
     return TETRIS_OK;
 }
 
+int tetris_enumerate_drops_dev(tetris_batch* b, const int32_t* d_idx, int n, const uint8_t* d_player, uint8_t* d_valid,
+                               int8_t* d_land_y, uint8_t* d_cleared, uint32_t* d_after) {
+    int rc = check_batch(b);
+    if (rc) return rc;
+    if (!d_valid || !d_land_y || !d_cleared) return fail(TETRIS_E_ARG, "valid/land_y/cleared are NULL");
+    if (n < 0 || (!d_idx && n > b->N)) return fail(TETRIS_E_ARG, "n out of range");
+    if (n == 0) return TETRIS_OK;
+    const size_t lanes = (size_t)n * 40;
+    dim3 grid((unsigned)((lanes + 255) / 256)), block(256);
+    if (b->P == 1)
+        hipLaunchKernelGGL(k_enumerate<1>, grid, block, 0, b->stream, b->d_state, b->N, n, d_idx, d_player, b->H, d_valid, d_land_y,
+                           d_cleared, d_after);
+    else
+        hipLaunchKernelGGL(k_enumerate<2>, grid, block, 0, b->stream, b->d_state, b->N, n, d_idx, d_player, b->H, d_valid, d_land_y,
+                           d_cleared, d_after);
+    HIP_TRY(hipGetLastError());
+    return TETRIS_OK;
+}
+
+int tetris_timer_start(tetris_batch* b) {
+    int rc = check_batch(b);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(b->ev0, b->stream));
+    return TETRIS_OK;
+}
+
+int tetris_timer_stop(tetris_batch* b, float* elapsed_ms) {
+    int rc = check_batch(b);
+    if (rc) return rc;
+    if (!elapsed_ms) return fail(TETRIS_E_ARG, "elapsed_ms is NULL");
+    HIP_TRY(hipEventRecord(b->ev1, b->stream));
+    HIP_TRY(hipEventSynchronize(b->ev1));
+    HIP_TRY(hipEventElapsedTime(elapsed_ms, b->ev0, b->ev1));
+    return TETRIS_OK;
+}
+
 int tetris_get_actions(tetris_batch* b, const int32_t* idx, int n, const uint8_t* player, uint8_t* keys, uint8_t* lens,
                        int32_t* count, int max_lists, int max_keys) {
     int rc = check_batch(b);

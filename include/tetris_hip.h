@@ -145,6 +145,10 @@ int tetris_set_dead(tetris_batch *b, const int32_t *idx, int n, const uint8_t *d
 int tetris_enumerate_drops(tetris_batch *b, const int32_t *idx, int n, const uint8_t *player, uint8_t *valid,
                            int8_t *land_y, uint8_t *cleared, uint32_t *after);
 
+/* same with device pointers (d_idx / d_player may be NULL), asynchronous on the batch's stream                        */
+int tetris_enumerate_drops_dev(tetris_batch *b, const int32_t *d_idx, int n, const uint8_t *d_player,
+                               uint8_t *d_valid, int8_t *d_land_y, uint8_t *d_cleared, uint32_t *d_after);
+
 /* replaces: PythonHandle.get_actions(player); masks[player].action (PythonHandle.cpp:190, TestField.cpp:64-415):
  * the reference's exact ordered key lists of the "place_block" action type — every (x, rotation) drop plus the
  * tuck / spin placements found by its backwards search — for the current piece of player[i] (NULL = player 0).
@@ -191,6 +195,11 @@ int tetris_split_stage_dev(tetris_batch *b, int stage, const uint8_t *d_rot, con
  * then the legacy default stream, which is what torch.cuda.current_stream() usually is; external == 0: back to the
  * batch's own stream (hip_stream ignored).                                                                        */
 int tetris_set_stream(tetris_batch *b, void *hip_stream, int external);
+
+/* HIP-event stopwatch on the batch's stream, for timing sequences of _dev calls: start records an event, stop records
+ * another, waits for it and returns the milliseconds in between.                                                    */
+int tetris_timer_start(tetris_batch *b);
+int tetris_timer_stop(tetris_batch *b, float *elapsed_ms);
 
 /* plumbing for zero-copy callers (torch / another HIP library)                                   */
 void *tetris_device_state(tetris_batch *b);            /* uint32 [NWORDS][P][N]                  */

@@ -57,4 +57,44 @@ dt = time.perf_counter() - t0
 out["get_actions_4096_boards"] = {"host_call_s_incl_pcie_and_python_lists": dt, "mean_lists_per_board": float(np.mean([len(l) for l in lists])),
                                   "max_lists": int(max(len(l) for l in lists)), "max_keys": int(max(len(a) for l in lists for a in l))}
 b.close()
+# device-side kernel times (HIP events on the batch's stream, outputs stay in HBM): enumerate_drops and observe_packed
+import torch  # noqa: E402
+
+def ptr(t):
+    return C.c_void_p(t.data_ptr())
+
+b = pkg.TetrisBatch(16384, 1, 20, 10, seeds=np.arange(16384))
+advance(b, 12)
+n = 16384
+dv = dict(dtype=torch.uint8, device="cuda")
+valid, land, cleared = torch.zeros(n * 40, **dv), torch.zeros(n * 40, dtype=torch.int8, device="cuda"), torch.zeros(n * 40, **dv)
+after = torch.zeros(n * 400, dtype=torch.int32, device="cuda")
+torch.cuda.synchronize()
+for _ in range(5):
+    b._check(b.lib.tetris_enumerate_drops_dev(b._h, None, n, None, ptr(valid), ptr(land), ptr(cleared), ptr(after)))
+b.timer_start()
+reps = 200
+for _ in range(reps):
+    b._check(b.lib.tetris_enumerate_drops_dev(b._h, None, n, None, ptr(valid), ptr(land), ptr(cleared), ptr(after)))
+us = b.timer_stop() * 1e3 / reps
+bytes_per_call = n * 44 + n * 40 * 43
+out["C4_enumerate_drops_16k_device"] = {"us_per_call": us, "afterstates_per_s": n * 40 / (us * 1e-6), "algorithmic_bytes": bytes_per_call,
+                                        "GBps": bytes_per_call / (us * 1e-6) / 1e9, "frac_of_8TBps": bytes_per_call / (us * 1e-6) / 8e12}
+b.close()
+
+b = pkg.TetrisBatch(65536, 2, 20, 10, seeds=np.arange(65536))
+advance(b, 12)
+n = 65536
+visual, vector, piece = torch.zeros(2 * n * 200, **dv), torch.zeros(2 * n * 12, **dv), torch.zeros(2 * n, **dv)
+torch.cuda.synchronize()
+for _ in range(5):
+    b._check(b.lib.tetris_observe_packed_dev(b._h, None, n, None, ptr(visual), ptr(vector), ptr(piece)))
+b.timer_start()
+for _ in range(reps):
+    b._check(b.lib.tetris_observe_packed_dev(b._h, None, n, None, ptr(visual), ptr(vector), ptr(piece)))
+us = b.timer_stop() * 1e3 / reps
+bytes_per_call = 2 * n * (44 + 213)
+out["observe_packed_64k_2p_device"] = {"us_per_call": us, "player_boards_per_s": 2 * n / (us * 1e-6), "algorithmic_bytes": bytes_per_call,
+                                       "GBps": bytes_per_call / (us * 1e-6) / 1e9, "frac_of_8TBps": bytes_per_call / (us * 1e-6) / 8e12}
+b.close()
 print(json.dumps(out))

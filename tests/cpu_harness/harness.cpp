@@ -312,6 +312,11 @@ int tetris_enumerate_drops(tetris_batch* b, const int32_t* idx, int n, const uin
     return TETRIS_OK;
 }
 
+int tetris_enumerate_drops_dev(tetris_batch* b, const int32_t* idx, int n, const uint8_t* player, uint8_t* valid, int8_t* land_y,
+                               uint8_t* cleared, uint32_t* after) { return tetris_enumerate_drops(b, idx, n, player, valid, land_y, cleared, after); }
+int tetris_timer_start(tetris_batch*) { return TETRIS_OK; }
+int tetris_timer_stop(tetris_batch*, float* ms) { if (ms) *ms = 0.0f; return TETRIS_OK; }
+
 int tetris_get_actions(tetris_batch* b, const int32_t* idx, int n, const uint8_t* player, uint8_t* keys, uint8_t* lens, int32_t* count,
                        int max_lists, int max_keys) {
     int rc = check_idx(b, idx, n); if (rc) return rc;
