@@ -93,6 +93,47 @@ def cpu_baseline(n_players, height, budget_s):
     return out
 
 
+def bench_split(args, mod, dist, rank, world, local_rank):
+    """BASELINE config 5: opponents on different GPUs, RCCL all-gather for the garbage exchange (SplitOpponents)."""
+    if dist is None or world % 2:
+        raise SystemExit("--workload split needs an even number of ranks >= 2 (torch.distributed.run)")
+    import torch
+    N, pair = args.games, rank // 2
+    so = mod.SplitOpponents(N, side=rank % 2, peer=rank ^ 1, dist=dist, height=args.height, seeds=mod.episode_seeds(pair * N, N),
+                            device=local_rank, lib_path=os.environ.get("BENCH_LIB_PATH"))
+    so.batch.set_game_offset(pair * N)
+    so.rollout(args.warmup)
+    dist.barrier()
+    wall = so.rollout(args.steps, first_step=args.warmup)
+    dist.barrier()
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    t = torch.tensor([wall], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    tot = torch.tensor([int(x) for x in so.batch.rollout_totals()], dtype=torch.int64, device=dev)
+    if rank % 2:
+        tot[0] = 0                                   # episodes are counted once per game (by side 0)
+    dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    if rank == 0:
+        wall = float(t[0])
+        env_steps = (world // 2) * N * args.steps
+        per_step_us = wall * 1e6 / args.steps
+        algo = (ALGO_BYTES[2] // 2) * N                # one player-board of every game per GPU and step
+        achieved = algo / (per_step_us * 1e-6) / 1e9
+        print(json.dumps({
+            "metric": "env-steps/sec at 64k parallel 20x10 boards", "value": env_steps / wall, "unit": "env-steps/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall * 1e3 / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "config": {"workload": f"{N} two-player {args.height}x10 games per GPU pair, player 0 and player 1 on different GPUs, "
+                                   "random policy, auto-reset, garbage exchange = 3 all-gathers of 4 B per board per step",
+                       "games_per_pair": N, "players": 2, "parallelism": f"{world // 2} pairs, all-gather over {world} ranks"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "kernel": "k_split<0..2> + 3 all-gathers per step (wall time, not kernel time)",
+                         "algorithmic_bytes_per_launch": algo, "launch_us": per_step_us},
+            "episodes": int(tot[0]), "lines_cleared": int(tot[1]), "garbage_sent": int(tot[2]), "cpu_baseline": None}))
+    so.close()
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -103,6 +144,9 @@ def main():
     ap.add_argument("--height", type=int, default=20)
     ap.add_argument("--steps-per-launch", type=int, default=1, help=">1 = fused rollout (state stays in registers)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--workload", choices=["sharded", "split"], default="sharded",
+                    help="sharded (default): every rank owns whole games, no collective.  split: BASELINE config 5 — ranks 2k and 2k+1 "
+                         "hold player 0 / player 1 of the same games, garbage exchange by three RCCL all-gathers per step (even N only)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -115,7 +159,8 @@ def main():
 
         backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")     # "gloo" only to rehearse N>1 on a 1-GPU box
         local_rank = local_rank % max(1, torch.cuda.device_count())
-        torch.cuda.set_device(local_rank)
+        if torch.cuda.is_available():                              # (absent only in the CPU rehearsal with gloo + BENCH_LIB_PATH)
+            torch.cuda.set_device(local_rank)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -126,6 +171,8 @@ def main():
     ge.package()
     import importlib
     sharded = importlib.import_module("drl-tetris_amd.distributed")
+    if args.workload == "split":
+        return bench_split(args, sharded, dist, rank, world, local_rank)
     N, P, S = args.games, args.players, args.steps_per_launch
     # rank r owns global games [r*N, (r+1)*N): distinct policy stream and seed schedule per rank, no collective
     # on the data path; ShardedRollout brackets the timed launches with barrier + synchronize on both sides and

@@ -72,6 +72,8 @@ _SIGNATURES = {
     "tetris_observe_packed_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "tetris_create_split": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "tetris_split_stage_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "tetris_split_rollout_stage_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_uint32, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p]),
+    "tetris_rollout_totals": (C.c_int, [C.c_void_p, C.c_void_p]),
     "tetris_set_stream": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "tetris_rollout_random": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_uint32, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p]),
     "tetris_device_state": (C.c_void_p, [C.c_void_p]),
@@ -300,6 +302,15 @@ class TetrisBatch:
     def split_stage(self, stage, rot=None, trans=None, acting=None, words=None, out=None, done=None, lines=None, dead=None, ms=400):
         """One stage of a split-mode step; every argument is a raw device address (int) or None."""
         self._check(self.lib.tetris_split_stage_dev(self._h, int(stage), rot, trans, acting, int(ms), words, out, done, lines, dead))
+
+    def split_rollout_stage(self, stage, step, words=None, out=None, policy_seed=0xD71, ms=400):
+        self._check(self.lib.tetris_split_rollout_stage_dev(self._h, int(stage), int(policy_seed), int(step), int(ms), words, out))
+
+    def rollout_totals(self):
+        """-> uint64 [3]: cumulative episodes, lines cleared, garbage lines sent of this batch's built-in rollouts."""
+        t = np.zeros(3, np.uint64)
+        self._check(self.lib.tetris_rollout_totals(self._h, _p(t)))
+        return t
 
     def set_stream(self, stream_ptr, external=True):
         """Run on a caller-owned HIP stream (handle as int; 0 = the legacy default stream).  external=False: own stream."""

@@ -527,6 +527,41 @@ int tetris_split_stage_dev(tetris_batch* b, int stage, const uint8_t* d_rot, con
     return TETRIS_OK;
 }
 
+int tetris_split_rollout_stage_dev(tetris_batch* b, int stage, uint32_t policy_seed, uint64_t step, int ms, const uint32_t* d_words,
+                                   uint32_t* d_out) {
+    int rc = check_batch(b);
+    if (rc) return rc;
+    if (!b->split) return fail(TETRIS_E_ARG, "not a split batch (tetris_create_split)");
+    if (stage < 0 || stage > 2) return fail(TETRIS_E_ARG, "stage must be 0, 1 or 2");
+    if (stage < 2 && !d_out) return fail(TETRIS_E_ARG, "stages 0 and 1 need d_out");
+    if (stage > 0 && !d_words) return fail(TETRIS_E_ARG, "stages 1 and 2 need d_words");
+    KArgs a = base_args(b, b->N, nullptr);
+    a.ms = ms; a.policy_seed = policy_seed; a.first_step = step; a.steps = 1;
+    a.shadow = b->d_shadow; a.xw = d_words; a.xout = d_out;
+    dim3 grid((unsigned)((b->N + 255) / 256)), block(256);
+    if (stage == 0) hipLaunchKernelGGL((k_split<0, false>), grid, block, 0, b->stream, a);
+    else if (stage == 1) hipLaunchKernelGGL((k_split<1, false>), grid, block, 0, b->stream, a);
+    else hipLaunchKernelGGL((k_split<2, false>), grid, block, 0, b->stream, a);
+    HIP_TRY(hipGetLastError());
+    return TETRIS_OK;
+}
+
+int tetris_rollout_totals(tetris_batch* b, uint64_t totals[3]) {
+    int rc = check_batch(b);
+    if (rc) return rc;
+    if (!totals) return fail(TETRIS_E_ARG, "totals is NULL");
+    HIP_TRY(hipMemsetAsync(b->d_counters, 0, 8 * sizeof(unsigned long long), b->stream));
+    const int tot_blocks = b->N >= 65536 ? 64 : (b->N + 1023) / 1024;
+    hipLaunchKernelGGL(k_totals, dim3(tot_blocks), dim3(256), 0, b->stream, b->d_gstate, b->N, b->d_counters);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(b->h_status + 2, b->d_counters, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, b->stream));
+    if ((rc = finish_call(b))) return rc;
+    unsigned long long hc[3];
+    memcpy(hc, b->h_status + 2, sizeof hc);
+    for (int k = 0; k < 3; k++) totals[k] = hc[k];
+    return TETRIS_OK;
+}
+
 int tetris_sync(tetris_batch* b) {
     int rc = check_batch(b);
     if (rc) return rc;

@@ -198,12 +198,22 @@ TE_HD void split_body(const KArgs& a, int i, const uint32_t* shapes) {
     const bool from_shadow = STAGE == 1 && side == 1 && !(opp_a & XW_DIED);
     load_game<1>(from_shadow ? a.shadow : a.state, a.gstate, N, (size_t)i, g, TINT);
     Player& q = g.pl[0];
+    const uint32_t sent_before = q.lines_sent;
     if (STAGE == 0) {
-        const int acting = a.player ? a.player[i] : 0;
+        int acting, r, t;
+        if (a.rot) { acting = a.player ? a.player[i] : 0; r = a.rot[i] & 3; t = a.trans[i]; }
+        else {          // built-in synthetic policy, identical on both sides of a game
+            uint32_t w[4];
+            philox4x32_10(a.policy_seed, a.game_offset + (uint32_t)i, (uint32_t)a.first_step, (uint32_t)(a.first_step >> 32), w);
+            r = (int)(w[0] & 3u); t = (int)(w[1] % 10u); acting = (int)(a.first_step % 2ull);
+        }
         prefetch_next(cx, q, g.seed16, g.status);
-        if (!g.round_over && !q.dead && acting == side) play_rt(cx, q, a.rot[i] & 3, a.trans[i]);
+        if (!g.round_over && !q.dead && acting == side) play_rt(cx, q, r, t);
         if (side == 1) store_game<1>(a.state, a.gstate, N, (size_t)i, g, TINT);        // post-make, pre-settle
         a.xout[i] = split_settle(cx, g);
+        // rollout counter: side 1's loop-1 pass is speculative and the game words are not shadowed, so side 1 counts
+        // these lines at stage 1, once it knows the pass is committed
+        if (side == 0) g.roll_sent += (q.lines_sent - sent_before) & 0xFFFFu;
         store_game<1>(side == 1 ? a.shadow : a.state, a.gstate, N, (size_t)i, g, TINT);
     } else if (STAGE == 1) {
         uint32_t w;
@@ -216,9 +226,11 @@ TE_HD void split_body(const KArgs& a, int i, const uint32_t* shapes) {
             const int in1 = ((opp_a & XW_RAN) && !(opp_a & XW_DIED)) ? xw_sent(opp_a) : 0;
             if (!g.round_over && in1 > 0) q.incoming = q.incoming + (float)in1 / 1.0f;   // loop 1, PythonHandle.cpp:121
             const int in2 = (opp_b & XW_DIED) ? 0 : xw_sent(opp_b);                      // loop 2, :175
+            if (from_shadow && (my_a & XW_RAN) && !(my_a & XW_DIED)) g.roll_sent += (uint32_t)xw_sent(my_a);   // committed loop-1 lines
             w = split_tick(cx, g, a.ms, in2);
         }
         a.xout[i] = w;
+        g.roll_sent += (q.lines_sent - sent_before) & 0xFFFFu;
         store_game<1>(a.state, a.gstate, N, (size_t)i, g, TINT);
     } else {
         const uint32_t opp_b = a.xw[(size_t)(side == 0 ? 3 : 2) * a.n + i];
@@ -227,6 +239,10 @@ TE_HD void split_body(const KArgs& a, int i, const uint32_t* shapes) {
         if (a.done) a.done[i] = (uint8_t)done;
         if (a.lines) a.lines[i] = (uint8_t)q.reward;
         if (a.dead) a.dead[i] = (uint8_t)q.dead;
+        if (a.steps) {          // built-in rollout: counters and auto-reset, the same decision on both sides of the game
+            if (!q.dead) g.roll_lines += (unsigned)q.reward;
+            if (done) { g.episode++; reset_split(cx, g, episode_seed(a.game_offset + (uint32_t)i, g.episode)); }
+        }
         store_game<1>(a.state, a.gstate, N, (size_t)i, g, TINT);
     }
     if (g.status) {

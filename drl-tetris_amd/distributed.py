@@ -128,6 +128,34 @@ class SplitOpponents:
             t.cuda.current_stream(self.dev).synchronize()
         return self.done.cpu().numpy().copy(), self.lines.cpu().numpy().copy(), self.dead.cpu().numpy().copy()
 
+    def rollout(self, steps, first_step=0, policy_seed=0xD71, ms=400):
+        """`steps` env-steps of the built-in synthetic rollout on every game (policy, acting player and auto-reset are
+        computed on the device, identically on both sides): per step three kernels and three all-gathers, no host
+        synchronisation in between.  -> seconds (wall, after a final stream sync)."""
+        t, B, w = self.torch, self.batch, self.words
+        zero = t.zeros_like(self.out)
+        if self.on_gpu:
+            t.cuda.current_stream(self.dev).synchronize()
+        t0 = time.perf_counter()
+        for s in range(first_step, first_step + steps):
+            B.split_rollout_stage(0, s, out=self.out.data_ptr(), policy_seed=policy_seed, ms=ms)
+            w[0].copy_(self.out)
+            w[1].copy_(self._exchange(self.out))
+            if self.side == 0:
+                B.split_rollout_stage(1, s, words=w.data_ptr(), out=self.out.data_ptr(), policy_seed=policy_seed, ms=ms)
+                w[2].copy_(self.out)
+                self._exchange(self.out)
+                w[3].copy_(self._exchange(zero))
+            else:
+                w[2].copy_(self._exchange(zero))
+                B.split_rollout_stage(1, s, words=w.data_ptr(), out=self.out.data_ptr(), policy_seed=policy_seed, ms=ms)
+                w[3].copy_(self.out)
+                self._exchange(self.out)
+            B.split_rollout_stage(2, s, words=w.data_ptr(), policy_seed=policy_seed, ms=ms)
+        if self.on_gpu:
+            t.cuda.current_stream(self.dev).synchronize()
+        return time.perf_counter() - t0
+
     def reset(self, idx, seeds):
         if self.on_gpu:
             self.torch.cuda.current_stream(self.dev).synchronize()

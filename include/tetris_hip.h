@@ -190,6 +190,16 @@ int tetris_create_split(tetris_batch **out, int n_games, int side, int height, i
 int tetris_split_stage_dev(tetris_batch *b, int stage, const uint8_t *d_rot, const uint8_t *d_trans,
                            const uint8_t *d_acting, int ms, const uint32_t *d_words, uint32_t *d_out,
                            uint8_t *d_done, uint8_t *d_lines, uint8_t *d_dead);
+/* One stage of a split-mode step of the built-in synthetic rollout (same policy and reset-seed schedule as
+ * tetris_rollout_random, keyed by global game id and `step`; acting player = step mod 2): stage 0 draws the action on
+ * the device, stage 2 counts and auto-resets finished games — identically on both sides, so no host round trip is
+ * needed inside a rollout.  d_words / d_out as for tetris_split_stage_dev.                                          */
+int tetris_split_rollout_stage_dev(tetris_batch *b, int stage, uint32_t policy_seed, uint64_t step, int ms,
+                                   const uint32_t *d_words, uint32_t *d_out);
+/* cumulative counters of the built-in rollouts of this batch: totals[3] = {episodes, lines_cleared, garbage_sent}
+ * (sums of the per-game words; synchronous).                                                                       */
+int tetris_rollout_totals(tetris_batch *b, uint64_t totals[3]);
+
 /* Run the batch on a caller-owned HIP stream (e.g. torch's current stream) so that its kernels are ordered with the
  * caller's copies and collectives without host synchronisation.  external != 0: use `hip_stream` as given — NULL is
  * then the legacy default stream, which is what torch.cuda.current_stream() usually is; external == 0: back to the

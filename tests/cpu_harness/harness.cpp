@@ -209,6 +209,29 @@ int tetris_split_stage_dev(tetris_batch* b, int stage, const uint8_t* rot, const
     }
     return TETRIS_OK;
 }
+int tetris_split_rollout_stage_dev(tetris_batch* b, int stage, uint32_t policy_seed, uint64_t step, int ms, const uint32_t* words,
+                                   uint32_t* outw) {
+    if (!b->split) return fail(TETRIS_E_ARG, "not a split batch");
+    if (stage < 0 || stage > 2) return fail(TETRIS_E_ARG, "stage");
+    KArgs a = base_args(b, b->N, nullptr);
+    a.ms = ms; a.policy_seed = policy_seed; a.first_step = step; a.steps = 1;
+    a.shadow = b->shadow.data(); a.xw = words; a.xout = outw;
+    for (int i = 0; i < b->N; i++) {
+        if (stage == 0) split_body<0>(a, i, SHAPES.s);
+        else if (stage == 1) split_body<1>(a, i, SHAPES.s);
+        else split_body<2>(a, i, SHAPES.s);
+    }
+    return TETRIS_OK;
+}
+int tetris_rollout_totals(tetris_batch* b, uint64_t totals[3]) {
+    totals[0] = totals[1] = totals[2] = 0;
+    for (int i = 0; i < b->N; i++) {
+        unsigned long long t[3];
+        totals_of_game(b->gstate.data(), b->N, i, t);
+        totals[0] += t[0]; totals[1] += t[1]; totals[2] += t[2];
+    }
+    return TETRIS_OK;
+}
 int tetris_destroy(tetris_batch* b) { delete b; return TETRIS_OK; }
 int tetris_sync(tetris_batch* b) { return finish_call(b); }
 int tetris_set_game_offset(tetris_batch* b, uint64_t first) { b->game_offset = (uint32_t)first; return TETRIS_OK; }

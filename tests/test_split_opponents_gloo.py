@@ -97,3 +97,40 @@ def test_split_opponents_equal_colocated_game(tmp_path, scenario, pieces):
         assert np.array_equal(got["rec"]["field"][:, 0] > 0, rec["field"][:, side] > 0)
         assert np.array_equal(got["ro"], ro), side
         assert np.array_equal(got["lw"], lw), side
+
+
+STEPS_ROLLOUT = 300
+
+
+def _rollout_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ge.ROOT)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mod = __import__("importlib").import_module("drl-tetris_amd.distributed")
+    so = mod.SplitOpponents(N, side=rank, peer=1 - rank, dist=dist, seeds=orc.episode_seed(np.arange(N), 0), lib_path=ge.build_harness())
+    so.rollout(STEPS_ROLLOUT // 2)
+    so.rollout(STEPS_ROLLOUT - STEPS_ROLLOUT // 2, first_step=STEPS_ROLLOUT // 2)
+    rec, ro, lw = so.batch.observe()
+    np.savez(os.path.join(out_dir, f"roll{rank}.npz"), rec=rec, ro=ro, lw=lw, totals=so.batch.rollout_totals())
+    so.close()
+    dist.destroy_process_group()
+
+
+def test_split_rollout_equals_oracle_two_player_rollout(tmp_path):
+    """The device-driven split rollout (policy, acting player and auto-reset computed on the device, identically on both
+    ranks) against the oracle's co-located two-player rollout: counters and every board."""
+    ge.build_harness()
+    mp.spawn(_rollout_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    ref = orc.OracleBatch(N, 2, 20, 10, seeds=orc.episode_seed(np.arange(N), 0))
+    _, want = ref.rollout_random(STEPS_ROLLOUT)
+    rec, ro, lw = ref.observe()
+    got = [np.load(os.path.join(str(tmp_path), f"roll{s}.npz")) for s in (0, 1)]
+    episodes, lines, sent = int(want[1]), int(want[2]), int(want[3])
+    assert int(got[0]["totals"][0]) == episodes == int(got[1]["totals"][0]) and episodes > 0
+    assert int(got[0]["totals"][1]) + int(got[1]["totals"][1]) == lines
+    assert int(got[0]["totals"][2]) + int(got[1]["totals"][2]) == sent
+    for side in (0, 1):
+        for f in FIELDS:
+            assert np.array_equal(got[side]["rec"][f][:, 0], rec[f][:, side]), (side, f)
+        assert np.array_equal(got[side]["rec"]["field"][:, 0] > 0, rec["field"][:, side] > 0)
+        assert np.array_equal(got[side]["ro"], ro) and np.array_equal(got[side]["lw"], lw)
