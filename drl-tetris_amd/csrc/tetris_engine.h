@@ -138,8 +138,50 @@ struct Game {
 
 // ---------------------------------------------------------------- load / store (SoA, coalesced)
 // state[(w * P + p) * n + slot]; game words at gstate[w * n + slot]
+// one player-board: word w of this board lives at s[w * ws]
+TE_HD void load_player(const uint32_t* s, size_t ws, Player& q, bool tint) {
+    for (int c = 0; c < NCOL; c++) q.col[c] = ld_stream(&s[(size_t)(W_COL0 + c) * ws]);
+    if (tint)
+        for (int k = 0; k < 3; k++)
+            for (int c = 0; c < NCOL; c++) q.tint[k][c] = ld_stream(&s[(size_t)(W_TINT0 + 10 * k + c) * ws]);
+    uint32_t w = ld_stream(&s[(size_t)W_PIECE * ws]);
+    q.kind = w & 7; q.rot = (w >> 3) & 3; q.x = (int)((w >> 5) & 15) - 4; q.y = (w >> 9) & 31;
+    q.next = (w >> 14) & 7; q.dead = (w >> 17) & 1; q.lock_armed = (w >> 18) & 1; q.reward = (w >> 19) & 255;
+    w = ld_stream(&s[(size_t)W_MISC * ws]);
+    q.inc_count = w & 255; q.combo_count = (w >> 8) & 255; q.line_count = (w >> 16) & 255;
+    q.qlen = (w >> 24) & 15; q.q_overflow = (w >> 28) & 1;
+    q.time_ms = (int32_t)ld_stream(&s[(size_t)W_TIME * ws]);
+    w = ld_stream(&s[(size_t)W_DROPCOMBO * ws]);
+    q.drop_delay = w & 0xFFFF; q.combo_remaining = w >> 16;
+    q.drop_time = (int32_t)ld_stream(&s[(size_t)W_DROP_TIME * ws]);
+    q.speedup_time = (int32_t)ld_stream(&s[(size_t)W_SPEEDUP_TIME * ws]);
+    q.lock_time = (int32_t)ld_stream(&s[(size_t)W_LOCK_TIME * ws]);
+    q.combo_start = (int32_t)ld_stream(&s[(size_t)W_COMBO_START * ws]);
+    q.combo_time = (int32_t)ld_stream(&s[(size_t)W_COMBO_TIME * ws]);
+    q.incoming = u2f(ld_stream(&s[(size_t)W_INCOMING * ws]));
+    q.min_remaining = (int32_t)ld_stream(&s[(size_t)W_MIN_REMAINING * ws]);
+    q.piece_draws = ld_stream(&s[(size_t)W_PIECE_DRAWS * ws]);
+    q.hole_draws = ld_stream(&s[(size_t)W_HOLE_DRAWS * ws]);
+    q.pgroup = ld_stream(&s[(size_t)W_PIECE_GROUP * ws]);
+    w = ld_stream(&s[(size_t)W_STATS0 * ws]); q.lines_sent = w & 0xFFFF; q.lines_cleared = w >> 16;
+    w = ld_stream(&s[(size_t)W_STATS1 * ws]); q.lines_blocked = w & 0xFFFF; q.max_combo = w >> 16;
+    w = ld_stream(&s[(size_t)W_STATS2 * ws]); q.lines_seen = w & 0xFFFF; q.garbage_cleared = w >> 16;
+    q.q_loaded = q.qlen > 0;
+    q.pf_ok = 0; q.pf_raw.lo = 0; q.pf_raw.hi = 0;
+    for (int i = 0; i < FIFO_CAP; i++) { q.qcount[i] = 0; q.qdelay[i] = 0; }
+    if (q.q_loaded) {
+        for (int i = 0; i < FIFO_CAP / 2; i++) {
+            uint32_t cw = ld_stream(&s[(size_t)(W_FIFO_COUNT0 + i) * ws]);
+            q.qcount[2 * i] = (int16_t)(cw & 0xFFFF);
+            q.qcount[2 * i + 1] = (int16_t)(cw >> 16);
+        }
+        for (int i = 0; i < FIFO_CAP; i++) q.qdelay[i] = (int32_t)ld_stream(&s[(size_t)(W_FIFO_DELAY0 + i) * ws]);
+    }
+}
+
+// the per-game words
 template <int P>
-TE_HD void load_game(const uint32_t* state, const uint32_t* gstate, size_t n, size_t slot, Game<P>& g, bool tint = false) {
+TE_HD void load_game_words(const uint32_t* gstate, size_t n, size_t slot, Game<P>& g) {
     uint32_t meta = ld_stream(&gstate[(size_t)G_META * n + slot]);
     g.seed16 = meta & 0xFFFFu;
     g.round_over = (meta >> 16) & 1;
@@ -149,92 +191,60 @@ TE_HD void load_game(const uint32_t* state, const uint32_t* gstate, size_t n, si
     g.roll_lines = ld_stream(&gstate[(size_t)G_LINES * n + slot]);
     g.roll_sent = ld_stream(&gstate[(size_t)G_SENT * n + slot]);
     g.status = 0;
+}
+
+template <int P>
+TE_HD void load_game(const uint32_t* state, const uint32_t* gstate, size_t n, size_t slot, Game<P>& g, bool tint = false) {
+    load_game_words<P>(gstate, n, slot, g);
     TE_UNROLL
-    for (int p = 0; p < P; p++) {
-        Player& q = g.pl[p];
-        const uint32_t* s = state + (size_t)p * n + slot;
-        const size_t ws = (size_t)P * n;
-        for (int c = 0; c < NCOL; c++) q.col[c] = ld_stream(&s[(size_t)(W_COL0 + c) * ws]);
-        if (tint)
-            for (int k = 0; k < 3; k++)
-                for (int c = 0; c < NCOL; c++) q.tint[k][c] = ld_stream(&s[(size_t)(W_TINT0 + 10 * k + c) * ws]);
-        uint32_t w = ld_stream(&s[(size_t)W_PIECE * ws]);
-        q.kind = w & 7; q.rot = (w >> 3) & 3; q.x = (int)((w >> 5) & 15) - 4; q.y = (w >> 9) & 31;
-        q.next = (w >> 14) & 7; q.dead = (w >> 17) & 1; q.lock_armed = (w >> 18) & 1; q.reward = (w >> 19) & 255;
-        w = ld_stream(&s[(size_t)W_MISC * ws]);
-        q.inc_count = w & 255; q.combo_count = (w >> 8) & 255; q.line_count = (w >> 16) & 255;
-        q.qlen = (w >> 24) & 15; q.q_overflow = (w >> 28) & 1;
-        q.time_ms = (int32_t)ld_stream(&s[(size_t)W_TIME * ws]);
-        w = ld_stream(&s[(size_t)W_DROPCOMBO * ws]);
-        q.drop_delay = w & 0xFFFF; q.combo_remaining = w >> 16;
-        q.drop_time = (int32_t)ld_stream(&s[(size_t)W_DROP_TIME * ws]);
-        q.speedup_time = (int32_t)ld_stream(&s[(size_t)W_SPEEDUP_TIME * ws]);
-        q.lock_time = (int32_t)ld_stream(&s[(size_t)W_LOCK_TIME * ws]);
-        q.combo_start = (int32_t)ld_stream(&s[(size_t)W_COMBO_START * ws]);
-        q.combo_time = (int32_t)ld_stream(&s[(size_t)W_COMBO_TIME * ws]);
-        q.incoming = u2f(ld_stream(&s[(size_t)W_INCOMING * ws]));
-        q.min_remaining = (int32_t)ld_stream(&s[(size_t)W_MIN_REMAINING * ws]);
-        q.piece_draws = ld_stream(&s[(size_t)W_PIECE_DRAWS * ws]);
-        q.hole_draws = ld_stream(&s[(size_t)W_HOLE_DRAWS * ws]);
-        q.pgroup = ld_stream(&s[(size_t)W_PIECE_GROUP * ws]);
-        w = ld_stream(&s[(size_t)W_STATS0 * ws]); q.lines_sent = w & 0xFFFF; q.lines_cleared = w >> 16;
-        w = ld_stream(&s[(size_t)W_STATS1 * ws]); q.lines_blocked = w & 0xFFFF; q.max_combo = w >> 16;
-        w = ld_stream(&s[(size_t)W_STATS2 * ws]); q.lines_seen = w & 0xFFFF; q.garbage_cleared = w >> 16;
-        q.q_loaded = q.qlen > 0;
-        q.pf_ok = 0; q.pf_raw.lo = 0; q.pf_raw.hi = 0;
-        for (int i = 0; i < FIFO_CAP; i++) { q.qcount[i] = 0; q.qdelay[i] = 0; }
-        if (q.q_loaded) {
-            for (int i = 0; i < FIFO_CAP / 2; i++) {
-                uint32_t cw = ld_stream(&s[(size_t)(W_FIFO_COUNT0 + i) * ws]);
-                q.qcount[2 * i] = (int16_t)(cw & 0xFFFF);
-                q.qcount[2 * i + 1] = (int16_t)(cw >> 16);
-            }
-            for (int i = 0; i < FIFO_CAP; i++) q.qdelay[i] = (int32_t)ld_stream(&s[(size_t)(W_FIFO_DELAY0 + i) * ws]);
-        }
+    for (int p = 0; p < P; p++) load_player(state + (size_t)p * n + slot, (size_t)P * n, g.pl[p], tint);
+}
+
+TE_HD void store_player(uint32_t* s, size_t ws, const Player& q, bool tint) {
+    for (int c = 0; c < NCOL; c++) st_stream(&s[(size_t)(W_COL0 + c) * ws], q.col[c]);
+    if (tint)
+        for (int k = 0; k < 3; k++)
+            for (int c = 0; c < NCOL; c++) st_stream(&s[(size_t)(W_TINT0 + 10 * k + c) * ws], q.tint[k][c]);
+    st_stream(&s[(size_t)W_PIECE * ws], (uint32_t)q.kind | ((uint32_t)q.rot << 3) | ((uint32_t)(q.x + 4) << 5) | ((uint32_t)q.y << 9) |
+                              ((uint32_t)q.next << 14) | ((uint32_t)q.dead << 17) | ((uint32_t)q.lock_armed << 18) |
+                              ((uint32_t)(q.reward & 255) << 19));
+    st_stream(&s[(size_t)W_MISC * ws], (uint32_t)(q.inc_count & 255) | ((uint32_t)(q.combo_count & 255) << 8) |
+                             ((uint32_t)(q.line_count & 255) << 16) | ((uint32_t)q.qlen << 24) | ((uint32_t)q.q_overflow << 28));
+    st_stream(&s[(size_t)W_TIME * ws], (uint32_t)q.time_ms);
+    st_stream(&s[(size_t)W_DROPCOMBO * ws], ((uint32_t)q.drop_delay & 0xFFFF) | (q.combo_remaining << 16));
+    st_stream(&s[(size_t)W_DROP_TIME * ws], (uint32_t)q.drop_time);
+    st_stream(&s[(size_t)W_SPEEDUP_TIME * ws], (uint32_t)q.speedup_time);
+    st_stream(&s[(size_t)W_LOCK_TIME * ws], (uint32_t)q.lock_time);
+    st_stream(&s[(size_t)W_COMBO_START * ws], (uint32_t)q.combo_start);
+    st_stream(&s[(size_t)W_COMBO_TIME * ws], (uint32_t)q.combo_time);
+    st_stream(&s[(size_t)W_INCOMING * ws], f2u(q.incoming));
+    st_stream(&s[(size_t)W_MIN_REMAINING * ws], (uint32_t)q.min_remaining);
+    st_stream(&s[(size_t)W_PIECE_DRAWS * ws], q.piece_draws);
+    st_stream(&s[(size_t)W_HOLE_DRAWS * ws], q.hole_draws);
+    st_stream(&s[(size_t)W_PIECE_GROUP * ws], q.pgroup);
+    st_stream(&s[(size_t)W_STATS0 * ws], (q.lines_sent & 0xFFFF) | (q.lines_cleared << 16));
+    st_stream(&s[(size_t)W_STATS1 * ws], (q.lines_blocked & 0xFFFF) | (q.max_combo << 16));
+    st_stream(&s[(size_t)W_STATS2 * ws], (q.lines_seen & 0xFFFF) | (q.garbage_cleared << 16));
+    if (q.q_loaded || q.qlen > 0) {
+        for (int i = 0; i < FIFO_CAP / 2; i++)
+            st_stream(&s[(size_t)(W_FIFO_COUNT0 + i) * ws], ((uint32_t)q.qcount[2 * i] & 0xFFFF) | ((uint32_t)q.qcount[2 * i + 1] << 16));
+        for (int i = 0; i < FIFO_CAP; i++) st_stream(&s[(size_t)(W_FIFO_DELAY0 + i) * ws], (uint32_t)q.qdelay[i]);
     }
 }
 
 template <int P>
-TE_HD void store_game(uint32_t* state, uint32_t* gstate, size_t n, size_t slot, const Game<P>& g, bool tint = false) {
+TE_HD void store_game_words(uint32_t* gstate, size_t n, size_t slot, const Game<P>& g) {
     st_stream(&gstate[(size_t)G_META * n + slot], g.seed16 | ((uint32_t)g.round_over << 16) | ((uint32_t)(g.last_winner + 1) << 17) | (g.flags << 21));
     st_stream(&gstate[(size_t)G_EPISODE * n + slot], g.episode);
     st_stream(&gstate[(size_t)G_LINES * n + slot], g.roll_lines);
     st_stream(&gstate[(size_t)G_SENT * n + slot], g.roll_sent);
+}
+
+template <int P>
+TE_HD void store_game(uint32_t* state, uint32_t* gstate, size_t n, size_t slot, const Game<P>& g, bool tint = false) {
+    store_game_words<P>(gstate, n, slot, g);
     TE_UNROLL
-    for (int p = 0; p < P; p++) {
-        const Player& q = g.pl[p];
-        uint32_t* s = state + (size_t)p * n + slot;
-        const size_t ws = (size_t)P * n;
-        for (int c = 0; c < NCOL; c++) st_stream(&s[(size_t)(W_COL0 + c) * ws], q.col[c]);
-        if (tint)
-            for (int k = 0; k < 3; k++)
-                for (int c = 0; c < NCOL; c++) st_stream(&s[(size_t)(W_TINT0 + 10 * k + c) * ws], q.tint[k][c]);
-        st_stream(&s[(size_t)W_PIECE * ws], (uint32_t)q.kind | ((uint32_t)q.rot << 3) | ((uint32_t)(q.x + 4) << 5) | ((uint32_t)q.y << 9) |
-                                  ((uint32_t)q.next << 14) | ((uint32_t)q.dead << 17) | ((uint32_t)q.lock_armed << 18) |
-                                  ((uint32_t)(q.reward & 255) << 19));
-        st_stream(&s[(size_t)W_MISC * ws], (uint32_t)(q.inc_count & 255) | ((uint32_t)(q.combo_count & 255) << 8) |
-                                 ((uint32_t)(q.line_count & 255) << 16) | ((uint32_t)q.qlen << 24) | ((uint32_t)q.q_overflow << 28));
-        st_stream(&s[(size_t)W_TIME * ws], (uint32_t)q.time_ms);
-        st_stream(&s[(size_t)W_DROPCOMBO * ws], ((uint32_t)q.drop_delay & 0xFFFF) | (q.combo_remaining << 16));
-        st_stream(&s[(size_t)W_DROP_TIME * ws], (uint32_t)q.drop_time);
-        st_stream(&s[(size_t)W_SPEEDUP_TIME * ws], (uint32_t)q.speedup_time);
-        st_stream(&s[(size_t)W_LOCK_TIME * ws], (uint32_t)q.lock_time);
-        st_stream(&s[(size_t)W_COMBO_START * ws], (uint32_t)q.combo_start);
-        st_stream(&s[(size_t)W_COMBO_TIME * ws], (uint32_t)q.combo_time);
-        st_stream(&s[(size_t)W_INCOMING * ws], f2u(q.incoming));
-        st_stream(&s[(size_t)W_MIN_REMAINING * ws], (uint32_t)q.min_remaining);
-        st_stream(&s[(size_t)W_PIECE_DRAWS * ws], q.piece_draws);
-        st_stream(&s[(size_t)W_HOLE_DRAWS * ws], q.hole_draws);
-        st_stream(&s[(size_t)W_PIECE_GROUP * ws], q.pgroup);
-        st_stream(&s[(size_t)W_STATS0 * ws], (q.lines_sent & 0xFFFF) | (q.lines_cleared << 16));
-        st_stream(&s[(size_t)W_STATS1 * ws], (q.lines_blocked & 0xFFFF) | (q.max_combo << 16));
-        st_stream(&s[(size_t)W_STATS2 * ws], (q.lines_seen & 0xFFFF) | (q.garbage_cleared << 16));
-        if (q.q_loaded || q.qlen > 0) {
-            for (int i = 0; i < FIFO_CAP / 2; i++)
-                st_stream(&s[(size_t)(W_FIFO_COUNT0 + i) * ws], ((uint32_t)q.qcount[2 * i] & 0xFFFF) | ((uint32_t)q.qcount[2 * i + 1] << 16));
-            for (int i = 0; i < FIFO_CAP; i++) st_stream(&s[(size_t)(W_FIFO_DELAY0 + i) * ws], (uint32_t)q.qdelay[i]);
-        }
-    }
+    for (int p = 0; p < P; p++) store_player(state + (size_t)p * n + slot, (size_t)P * n, g.pl[p], tint);
 }
 
 // ---------------------------------------------------------------- board primitives
