@@ -37,9 +37,15 @@ TE_HD int clz32(uint32_t v) { return __builtin_clz(v); }
 // State words are touched exactly once per launch and next read by another launch (possibly on another
 // XCD): stream them past the caches (`nt`), which also leaves no dirty L2 lines for the end-of-kernel
 // write-back to drain.
+#ifndef TE_LD_NT
+#define TE_LD_NT 1
+#endif
+#ifndef TE_ST_NT
+#define TE_ST_NT 1
+#endif
 #if defined(__HIP_DEVICE_COMPILE__)
-TE_HD uint32_t ld_stream(const uint32_t* p) { return __builtin_nontemporal_load(p); }
-TE_HD void st_stream(uint32_t* p, uint32_t v) { __builtin_nontemporal_store(v, p); }
+TE_HD uint32_t ld_stream(const uint32_t* p) { return TE_LD_NT ? __builtin_nontemporal_load(p) : *p; }
+TE_HD void st_stream(uint32_t* p, uint32_t v) { if (TE_ST_NT) __builtin_nontemporal_store(v, p); else *p = v; }
 #else
 TE_HD uint32_t ld_stream(const uint32_t* p) { return *p; }
 TE_HD void st_stream(uint32_t* p, uint32_t v) { *p = v; }
