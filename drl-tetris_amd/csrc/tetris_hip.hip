@@ -706,12 +706,22 @@ static int stage_keys(tetris_batch* b, int n, const uint8_t* keys, const uint8_t
     uint8_t* hl = (uint8_t*)b->s_in1.h;
     for (int i = 0; i < n; i++)
         for (int p = 0; p < P; p++) {
-            int len = lens[(size_t)i * P + p];
+            const int len = lens[(size_t)i * P + p];
             if (len > max_keys) return fail(TETRIS_E_ARG, "lens[i][p] > max_keys");
             hl[(size_t)p * n + i] = (uint8_t)len;
-            for (int k = 0; k < max_keys; k++)
-                hk[((size_t)k * P + p) * n + i] = keys[((size_t)i * P + p) * max_keys + k];
         }
+    // [n][P][K] -> [K][P][n], blocked over games so that reads stay in L1 and every write run is contiguous
+    // (the naive order writes with a stride of n bytes: 52 ms instead of ~2 ms for 64k two-player games)
+    const int BLK = 512;
+    for (int i0 = 0; i0 < n; i0 += BLK) {
+        const int i1 = i0 + BLK < n ? i0 + BLK : n;
+        for (int k = 0; k < max_keys; k++)
+            for (int p = 0; p < P; p++) {
+                uint8_t* dst = hk + ((size_t)k * P + p) * n;
+                const uint8_t* src = keys + (size_t)p * max_keys + k;
+                for (int i = i0; i < i1; i++) dst[i] = src[(size_t)i * P * max_keys];
+            }
+    }
     HIP_TRY(hipMemcpyAsync(b->s_in0.d, hk, (size_t)n * P * max_keys, hipMemcpyHostToDevice, b->stream));
     HIP_TRY(hipMemcpyAsync(b->s_in1.d, hl, (size_t)n * P, hipMemcpyHostToDevice, b->stream));
     a.keys = (const uint8_t*)b->s_in0.d; a.lens = (const uint8_t*)b->s_in1.d; a.max_keys = max_keys;
