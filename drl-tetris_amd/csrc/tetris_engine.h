@@ -104,6 +104,7 @@ struct Ctx {
     int H;
     uint32_t floor_bits;             // ~0u << H
     bool tint;                       // colour planes are tracked (compile-time constant in every kernel)
+    bool queue;                      // garbage queue / incoming lines can exist (false in 1-player kernels: nothing ever sends)
 };
 
 // ---------------------------------------------------------------- one player-board in registers
@@ -145,7 +146,7 @@ struct Game {
 // ---------------------------------------------------------------- load / store (SoA, coalesced)
 // state[(w * P + p) * n + slot]; game words at gstate[w * n + slot]
 // one player-board: word w of this board lives at s[w * ws]
-TE_HD void load_player(const uint32_t* s, size_t ws, Player& q, bool tint) {
+TE_HD void load_player(const uint32_t* s, size_t ws, Player& q, bool tint, bool queue = true) {
     for (int c = 0; c < NCOL; c++) q.col[c] = ld_stream(&s[(size_t)(W_COL0 + c) * ws]);
     if (tint)
         for (int k = 0; k < 3; k++)
@@ -172,9 +173,10 @@ TE_HD void load_player(const uint32_t* s, size_t ws, Player& q, bool tint) {
     w = ld_stream(&s[(size_t)W_STATS0 * ws]); q.lines_sent = w & 0xFFFF; q.lines_cleared = w >> 16;
     w = ld_stream(&s[(size_t)W_STATS1 * ws]); q.lines_blocked = w & 0xFFFF; q.max_combo = w >> 16;
     w = ld_stream(&s[(size_t)W_STATS2 * ws]); q.lines_seen = w & 0xFFFF; q.garbage_cleared = w >> 16;
-    q.q_loaded = q.qlen > 0;
+    q.q_loaded = queue && q.qlen > 0;
     q.pf_ok = 0; q.pf_raw.lo = 0; q.pf_raw.hi = 0;
-    for (int i = 0; i < FIFO_CAP; i++) { q.qcount[i] = 0; q.qdelay[i] = 0; }
+    if (queue)
+        for (int i = 0; i < FIFO_CAP; i++) { q.qcount[i] = 0; q.qdelay[i] = 0; }
     if (q.q_loaded) {
         for (int i = 0; i < FIFO_CAP / 2; i++) {
             uint32_t cw = ld_stream(&s[(size_t)(W_FIFO_COUNT0 + i) * ws]);
@@ -200,13 +202,13 @@ TE_HD void load_game_words(const uint32_t* gstate, size_t n, size_t slot, Game<P
 }
 
 template <int P>
-TE_HD void load_game(const uint32_t* state, const uint32_t* gstate, size_t n, size_t slot, Game<P>& g, bool tint = false) {
+TE_HD void load_game(const uint32_t* state, const uint32_t* gstate, size_t n, size_t slot, Game<P>& g, bool tint = false, bool queue = true) {
     load_game_words<P>(gstate, n, slot, g);
     TE_UNROLL
-    for (int p = 0; p < P; p++) load_player(state + (size_t)p * n + slot, (size_t)P * n, g.pl[p], tint);
+    for (int p = 0; p < P; p++) load_player(state + (size_t)p * n + slot, (size_t)P * n, g.pl[p], tint, queue);
 }
 
-TE_HD void store_player(uint32_t* s, size_t ws, const Player& q, bool tint) {
+TE_HD void store_player(uint32_t* s, size_t ws, const Player& q, bool tint, bool queue = true) {
     for (int c = 0; c < NCOL; c++) st_stream(&s[(size_t)(W_COL0 + c) * ws], q.col[c]);
     if (tint)
         for (int k = 0; k < 3; k++)
@@ -231,7 +233,7 @@ TE_HD void store_player(uint32_t* s, size_t ws, const Player& q, bool tint) {
     st_stream(&s[(size_t)W_STATS0 * ws], (q.lines_sent & 0xFFFF) | (q.lines_cleared << 16));
     st_stream(&s[(size_t)W_STATS1 * ws], (q.lines_blocked & 0xFFFF) | (q.max_combo << 16));
     st_stream(&s[(size_t)W_STATS2 * ws], (q.lines_seen & 0xFFFF) | (q.garbage_cleared << 16));
-    if (q.q_loaded || q.qlen > 0) {
+    if (queue && (q.q_loaded || q.qlen > 0)) {
         for (int i = 0; i < FIFO_CAP / 2; i++)
             st_stream(&s[(size_t)(W_FIFO_COUNT0 + i) * ws], ((uint32_t)q.qcount[2 * i] & 0xFFFF) | ((uint32_t)q.qcount[2 * i + 1] << 16));
         for (int i = 0; i < FIFO_CAP; i++) st_stream(&s[(size_t)(W_FIFO_DELAY0 + i) * ws], (uint32_t)q.qdelay[i]);
@@ -247,10 +249,10 @@ TE_HD void store_game_words(uint32_t* gstate, size_t n, size_t slot, const Game<
 }
 
 template <int P>
-TE_HD void store_game(uint32_t* state, uint32_t* gstate, size_t n, size_t slot, const Game<P>& g, bool tint = false) {
+TE_HD void store_game(uint32_t* state, uint32_t* gstate, size_t n, size_t slot, const Game<P>& g, bool tint = false, bool queue = true) {
     store_game_words<P>(gstate, n, slot, g);
     TE_UNROLL
-    for (int p = 0; p < P; p++) store_player(state + (size_t)p * n + slot, (size_t)P * n, g.pl[p], tint);
+    for (int p = 0; p < P; p++) store_player(state + (size_t)p * n + slot, (size_t)P * n, g.pl[p], tint, queue);
 }
 
 // ---------------------------------------------------------------- board primitives
@@ -512,10 +514,10 @@ TE_HD bool spawn_next(const Ctx& cx, Player& q, uint32_t seed16, uint32_t& statu
 }
 
 // gamePlay.cpp:160-171 sendLines (+ Combo.cpp:50-52 noClear)
-TE_HD int score_clears(Player& q, int cleared) {
+TE_HD int score_clears(const Ctx& cx, Player& q, int cleared) {
     q.lines_cleared = (q.lines_cleared + (uint32_t)cleared) & 0xFFFFu;
     if (cleared == 0) { q.combo_time -= 200; return 0; }
-    int amount = q_block(q, cleared - 1, q.time_ms, true);
+    int amount = cx.queue ? q_block(q, cleared - 1, q.time_ms, true) : cleared - 1;
     q.lines_sent = (q.lines_sent + (uint32_t)amount) & 0xFFFFu;
     combo_gain(q, q.time_ms, cleared);
     return amount;
@@ -535,7 +537,7 @@ TE_HD int settle(const Ctx& cx, Player& q, uint32_t seed16, uint32_t& status) {
 #if defined(TE_ABLATE) && (TE_ABLATE & 8)
     return 0;                                        // diagnostic build: no clear / spawn
 #endif
-    int sent = score_clears(q, clear_rows(cx, q));
+    int sent = score_clears(cx, q, clear_rows(cx, q));
     if (spawn_next(cx, q, seed16, status)) return -1;
     return sent;
 }
@@ -595,15 +597,17 @@ TE_HD int tick(const Ctx& cx, Player& q, int ms, uint32_t seed16, uint32_t& stat
         lock_piece(cx, q);                                                  // gamePlay.cpp:38-46 hd
         return settle(cx, q, seed16, status);
     }
-    int whole = 0;
-    while (q.incoming >= 1.0f) { whole++; q.incoming = q.incoming - 1.f; }
-    if (whole) q_add(q, whole, q.time_ms, status);
+    if (cx.queue) {
+        int whole = 0;
+        while (q.incoming >= 1.0f) { whole++; q.incoming = q.incoming - 1.f; }
+        if (whole) q_add(q, whole, q.time_ms, status);
+    }
     int sent = combo_expire(cx, q, q.time_ms);
     if (sent) {
-        sent = q_block(q, sent, q.time_ms, false);
+        if (cx.queue) sent = q_block(q, sent, q.time_ms, false);
         q.lines_sent = (q.lines_sent + (uint32_t)sent) & 0xFFFFu;
     }
-    if (q_release(q, q.time_ms))
+    if (cx.queue && q_release(q, q.time_ms))
         if (push_garbage(cx, q, seed16, status)) return -1;
     return sent;
 }
@@ -616,7 +620,8 @@ TE_HD void restart_player(const Ctx& cx, Player& q, uint32_t seed16, uint32_t& s
         for (int k = 0; k < 3; k++)
             for (int c = 0; c < NCOL; c++) q.tint[k][c] = 0;
     q.qlen = 0; q.q_overflow = 0; q.lines_blocked = 0; q.min_remaining = 1000;
-    for (int i = 0; i < FIFO_CAP; i++) { q.qcount[i] = 0; q.qdelay[i] = 0; }
+    if (cx.queue)
+        for (int i = 0; i < FIFO_CAP; i++) { q.qcount[i] = 0; q.qdelay[i] = 0; }
     q.combo_start = 0; q.combo_time = 0; q.max_combo = 0; q.combo_count = 0; q.line_count = 0;
     q.lines_sent = 0; q.lines_cleared = 0; q.garbage_cleared = 0;
     q.speedup_time = 0; q.drop_delay = 1000; q.drop_time = 0; q.lock_time = 0; q.lock_armed = 0;
@@ -1067,7 +1072,7 @@ TE_HD int finish_game(const Ctx& cx, Game<P>& g, int ms) {
         alive++;
         q.reward = (int)((q.lines_cleared - q.lines_seen) & 0xFFu);
         q.lines_seen = q.lines_cleared;
-        q.inc_count = q_total(q) & 255;
+        q.inc_count = cx.queue ? (q_total(q) & 255) : 0;
     }
     if ((P > 1 && alive < 2) || !alive) { g.round_over = 1; return 1; }
     return 0;

@@ -47,7 +47,7 @@ enum Mode { M_INIT, M_RESET, M_MAKE, M_FINISH, M_STEP_KEYS, M_STEP_RT, M_ROLLOUT
 
 struct LaneCounters { unsigned long long steps, episodes, lines, sent; };   // used by the CPU test harness only
 
-TE_HD Ctx make_ctx(const KArgs& a, const uint32_t* shapes, bool tint = false) {
+TE_HD Ctx make_ctx(const KArgs& a, const uint32_t* shapes, bool tint = false, bool queue = true) {
     Ctx cx;
     cx.shapes = shapes;
     cx.table = a.table;
@@ -58,6 +58,7 @@ TE_HD Ctx make_ctx(const KArgs& a, const uint32_t* shapes, bool tint = false) {
     cx.H = a.H;
     cx.floor_bits = ~0u << a.H;
     cx.tint = tint;
+    cx.queue = queue;
     return cx;
 }
 
@@ -98,7 +99,7 @@ TE_HD void make_rt(const Ctx& cx, Game<P>& g, int player, int r, int t) {
 template <int P, int MODE, bool TINT = false>
 TE_HD void game_load(const KArgs& a, int i, Game<P>& g) {
     const size_t slot = a.idx ? (size_t)a.idx[i] : (size_t)i;
-    if (MODE != M_INIT && MODE != M_SPLIT_INIT) load_game<P>(a.state, a.gstate, (size_t)a.n_games, slot, g, TINT);
+    if (MODE != M_INIT && MODE != M_SPLIT_INIT) load_game<P>(a.state, a.gstate, (size_t)a.n_games, slot, g, TINT, P > 1);
 }
 
 // Phase 2: step and store.
@@ -106,7 +107,7 @@ template <int P, int MODE, bool TINT = false>
 TE_HD void game_run(const KArgs& a, int i, const uint32_t* shapes, Game<P>& g, LaneCounters& cnt) {
     const size_t N = (size_t)a.n_games;
     const size_t slot = a.idx ? (size_t)a.idx[i] : (size_t)i;
-    Ctx cx = make_ctx(a, shapes, TINT);
+    Ctx cx = make_ctx(a, shapes, TINT, P > 1 || MODE == M_SPLIT_INIT || MODE == M_SPLIT_RESET);
     if (MODE == M_INIT) init_game<P>(cx, g, (uint32_t)(a.seeds ? (uint16_t)a.seeds[i] : 0));
     if (MODE == M_SPLIT_INIT) {           // a.steps carries the side this batch holds
         init_game<P>(cx, g, (uint32_t)(a.seeds ? (uint16_t)a.seeds[i] : 0));
@@ -174,7 +175,7 @@ TE_HD void game_run(const KArgs& a, int i, const uint32_t* shapes, Game<P>& g, L
             }
         }
     }
-    store_game<P>(a.state, a.gstate, N, slot, g, TINT);
+    store_game<P>(a.state, a.gstate, N, slot, g, TINT, P > 1 || MODE == M_SPLIT_INIT || MODE == M_SPLIT_RESET);   // 1-player: FIFO words stay as zeroed at creation
     if (g.status) {
 #if defined(__HIP_DEVICE_COMPILE__)
         atomicOr(a.status, g.status);
@@ -352,7 +353,7 @@ TE_HD void enumerate_body(const uint32_t* state, int n_games, size_t t, const in
     const uint32_t w = s[(size_t)W_PIECE * ws];
     const int kind = w & 7, cur_rot = (w >> 3) & 3;
     Ctx cx;
-    cx.shapes = shapes; cx.H = H; cx.floor_bits = ~0u << H; cx.tint = false;
+    cx.shapes = shapes; cx.H = H; cx.floor_bits = ~0u << H; cx.tint = false; cx.queue = true;
     const int n_rot = kind == 6 ? 1 : (kind == 4 || kind == 2 || kind == 3) ? 2 : 4;     // TestField.cpp:71-109
     const int rot = kind == 6 ? cur_rot : r;                                               // O is used as it stands
     const uint32_t shape = shapes[((kind & 7) << 2) | rot];
@@ -388,7 +389,7 @@ TE_HD void actions_body(const uint32_t* state, int n_games, size_t t, const int3
     const uint32_t w = s[(size_t)W_PIECE * ws];
     const int kind = w & 7, cur_rot = (w >> 3) & 3;
     Ctx cx;
-    cx.shapes = shapes; cx.H = H; cx.floor_bits = ~0u << H; cx.tint = false;
+    cx.shapes = shapes; cx.H = H; cx.floor_bits = ~0u << H; cx.tint = false; cx.queue = true;
     const int n_rot = kind == 6 ? 1 : (kind == 4 || kind == 2 || kind == 3) ? 2 : 4;
     pr.q.kind = kind; pr.q.rot = kind == 6 ? cur_rot : r; pr.q.x = xi - 1; pr.q.y = 0;
     pr.spawn = spawn_rot(kind);
