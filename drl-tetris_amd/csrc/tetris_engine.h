@@ -157,6 +157,7 @@ TE_HD void load_player(const uint32_t* s, size_t ws, Player& q, bool tint, bool 
     w = ld_stream(&s[(size_t)W_MISC * ws]);
     q.inc_count = w & 255; q.combo_count = (w >> 8) & 255; q.line_count = (w >> 16) & 255;
     q.qlen = (w >> 24) & 15; q.q_overflow = (w >> 28) & 1;
+    if (!queue) { q.inc_count = 0; q.qlen = 0; q.q_overflow = 0; }      // invariants of a game without opponents
     q.time_ms = (int32_t)ld_stream(&s[(size_t)W_TIME * ws]);
     w = ld_stream(&s[(size_t)W_DROPCOMBO * ws]);
     q.drop_delay = w & 0xFFFF; q.combo_remaining = w >> 16;
@@ -165,10 +166,12 @@ TE_HD void load_player(const uint32_t* s, size_t ws, Player& q, bool tint, bool 
     q.lock_time = (int32_t)ld_stream(&s[(size_t)W_LOCK_TIME * ws]);
     q.combo_start = (int32_t)ld_stream(&s[(size_t)W_COMBO_START * ws]);
     q.combo_time = (int32_t)ld_stream(&s[(size_t)W_COMBO_TIME * ws]);
-    q.incoming = u2f(ld_stream(&s[(size_t)W_INCOMING * ws]));
-    q.min_remaining = (int32_t)ld_stream(&s[(size_t)W_MIN_REMAINING * ws]);
+    // nobody can send garbage to a single player: incoming lines, hole draws and the queue timer never leave their
+    // reset values (0, 0, 1000), so 1-player kernels neither load nor (for the two zeros) store these words
+    q.incoming = queue ? u2f(ld_stream(&s[(size_t)W_INCOMING * ws])) : 0.0f;
+    q.min_remaining = queue ? (int32_t)ld_stream(&s[(size_t)W_MIN_REMAINING * ws]) : 1000;
     q.piece_draws = ld_stream(&s[(size_t)W_PIECE_DRAWS * ws]);
-    q.hole_draws = ld_stream(&s[(size_t)W_HOLE_DRAWS * ws]);
+    q.hole_draws = queue ? ld_stream(&s[(size_t)W_HOLE_DRAWS * ws]) : 0u;
     q.pgroup = ld_stream(&s[(size_t)W_PIECE_GROUP * ws]);
     w = ld_stream(&s[(size_t)W_STATS0 * ws]); q.lines_sent = w & 0xFFFF; q.lines_cleared = w >> 16;
     w = ld_stream(&s[(size_t)W_STATS1 * ws]); q.lines_blocked = w & 0xFFFF; q.max_combo = w >> 16;
@@ -225,10 +228,10 @@ TE_HD void store_player(uint32_t* s, size_t ws, const Player& q, bool tint, bool
     st_stream(&s[(size_t)W_LOCK_TIME * ws], (uint32_t)q.lock_time);
     st_stream(&s[(size_t)W_COMBO_START * ws], (uint32_t)q.combo_start);
     st_stream(&s[(size_t)W_COMBO_TIME * ws], (uint32_t)q.combo_time);
-    st_stream(&s[(size_t)W_INCOMING * ws], f2u(q.incoming));
+    if (queue) st_stream(&s[(size_t)W_INCOMING * ws], f2u(q.incoming));
     st_stream(&s[(size_t)W_MIN_REMAINING * ws], (uint32_t)q.min_remaining);
     st_stream(&s[(size_t)W_PIECE_DRAWS * ws], q.piece_draws);
-    st_stream(&s[(size_t)W_HOLE_DRAWS * ws], q.hole_draws);
+    if (queue) st_stream(&s[(size_t)W_HOLE_DRAWS * ws], q.hole_draws);
     st_stream(&s[(size_t)W_PIECE_GROUP * ws], q.pgroup);
     st_stream(&s[(size_t)W_STATS0 * ws], (q.lines_sent & 0xFFFF) | (q.lines_cleared << 16));
     st_stream(&s[(size_t)W_STATS1 * ws], (q.lines_blocked & 0xFFFF) | (q.max_combo << 16));

@@ -99,7 +99,7 @@ TE_HD void make_rt(const Ctx& cx, Game<P>& g, int player, int r, int t) {
 template <int P, int MODE, bool TINT = false>
 TE_HD void game_load(const KArgs& a, int i, Game<P>& g) {
     const size_t slot = a.idx ? (size_t)a.idx[i] : (size_t)i;
-    if (MODE != M_INIT && MODE != M_SPLIT_INIT) load_game<P>(a.state, a.gstate, (size_t)a.n_games, slot, g, TINT, P > 1);
+    if (MODE != M_INIT && MODE != M_SPLIT_INIT) load_game<P>(a.state, a.gstate, (size_t)a.n_games, slot, g, TINT, P > 1 || MODE == M_SPLIT_RESET);   // split batches: 1-player layout WITH a queue
 }
 
 // Phase 2: step and store.

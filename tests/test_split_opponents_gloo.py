@@ -13,6 +13,7 @@ import __graft_entry__ as ge
 from oracle import oracle as orc
 
 N, STEPS = 160, 260
+CHECK_EVERY = 20
 FIELDS = ["x", "y", "piece", "cur_rot", "next", "dead", "reward", "inc_count", "combo_count", "combo_remaining", "time_ms", "incoming",
           "fifo_len", "fifo_count", "fifo_delay", "min_remaining", "lines_sent", "lines_cleared", "lines_blocked", "piece_draws",
           "hole_draws", "drop_time", "lock_time", "lock_armed", "combo_start", "combo_time"]
@@ -48,7 +49,7 @@ def _worker(rank, world, port, out_dir, scenario, pieces):
     mod = __import__("importlib").import_module("drl-tetris_amd.distributed")
     seeds = orc.episode_seed(np.arange(N), 0)
     so = mod.SplitOpponents(N, side=rank, peer=1 - rank, dist=dist, seeds=seeds, pieces=pieces, lib_path=ge.build_harness())
-    dones, episode = [], np.zeros(N, np.int64)
+    dones, episode, mid = [], np.zeros(N, np.int64), []
     for s in range(STEPS):
         rot, trans, acting = _actions(s, scenario)
         done, lines, dead = so.step_rt(rot, trans, acting)
@@ -57,8 +58,10 @@ def _worker(rank, world, port, out_dir, scenario, pieces):
         if len(idx):
             episode[idx] += 1
             so.reset(idx, orc.episode_seed(idx, episode[idx]))
+        if s % CHECK_EVERY == CHECK_EVERY - 1:
+            mid.append(so.batch.observe()[0])          # state right after this step's resets
     rec, ro, lw = so.batch.observe()
-    np.savez(os.path.join(out_dir, f"side{rank}.npz"), rec=rec, ro=ro, lw=lw, dones=np.stack(dones))
+    np.savez(os.path.join(out_dir, f"side{rank}.npz"), rec=rec, ro=ro, lw=lw, dones=np.stack(dones), mid=np.stack(mid))
     so.close()
     dist.destroy_process_group()
 
@@ -72,18 +75,21 @@ def test_split_opponents_equal_colocated_game(tmp_path, scenario, pieces):
     mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), scenario, pieces), nprocs=2, join=True)
     ref = orc.OracleBatch(N, 2, 20, 10, pieces=pieces, seeds=orc.episode_seed(np.arange(N), 0))
     episode = np.zeros(N, np.int64)
-    want_dones, sent_total, max_queue, max_combo = [], 0, 0, 0
+    want_dones, sent_total, max_queue, max_combo, want_mid = [], 0, 0, 0, []
     for s in range(STEPS):
         rot, trans, acting = _actions(s, scenario)
         d = ref.step_rt(rot, trans, acting)
         want_dones.append(d.copy())
         r = ref.observe()[0]
         max_queue, max_combo = max(max_queue, int(r["fifo_len"].max())), max(max_combo, int(r["max_combo"].max()))
+        pending_mid = s % CHECK_EVERY == CHECK_EVERY - 1
         idx = np.nonzero(d)[0].astype(np.int32)
         if len(idx):
             sent_total += int(ref.observe(idx)[0]["lines_sent"].sum())
             episode[idx] += 1
             ref.reset(idx, orc.episode_seed(idx, episode[idx]))
+        if pending_mid:
+            want_mid.append(ref.observe()[0])
     rec, ro, lw = ref.observe()
     if scenario == "o_only":     # the scenario must really exercise the exchange: queued garbage, combos, many lines
         assert sent_total > 300 and max_queue >= 2 and max_combo >= 2, (sent_total, max_queue, max_combo)
@@ -97,6 +103,9 @@ def test_split_opponents_equal_colocated_game(tmp_path, scenario, pieces):
         assert np.array_equal(got["rec"]["field"][:, 0] > 0, rec["field"][:, side] > 0)
         assert np.array_equal(got["ro"], ro), side
         assert np.array_equal(got["lw"], lw), side
+        for k, w in enumerate(want_mid):               # full state every CHECK_EVERY steps, resets included
+            for f in FIELDS:
+                assert np.array_equal(got["mid"][k][f][:, 0], w[f][:, side]), (side, f, "checkpoint", k)
 
 
 STEPS_ROLLOUT = 300
