@@ -217,7 +217,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic, "kernel": f"k_game<{P}, M_ROLLOUT>", "algorithmic_bytes_per_launch": algo_bytes,
+                "traffic": traffic, "kernel": "k_duo<M_ROLLOUT>" if (P == 2 and S == 1) else f"k_game<{P}, M_ROLLOUT>", "algorithmic_bytes_per_launch": algo_bytes,
                 "launch_us": launch_us,
             },
             "episodes": int(counters[1]), "lines_cleared": int(counters[2]), "garbage_sent": int(counters[3]),
