@@ -261,3 +261,87 @@ class tetris_environment_vector:
         width = max(len(k) for k in self.settings)
         body = "".join("\t{:{}}\t{}\n".format(k, width, v) for k, v in self.settings.items())
         return "<tetris_vector_env>" + "".join("tetris_environment settings:\n" + body for _ in self._idx(env)) + "</tetris_vector_env>"
+
+
+class tetris_environment:
+    """Single-game environment with the reference's method signatures (environment/tetris_environment.py:11-227), as the
+    agents use it for their `sandbox` (agents/sherlock_agent/sherlock_agent.py:94; agents/sherlock_agent/sherlock_utils.py:13-20;
+    agents/random_agent.py:31-35): `get_actions(state, player)`, `simulate_actions`, `simulate_all_actions(state, player)`,
+    `perform_action(action, player) -> (reward, done)`, `get_state()`, `set`, `copy`, `reset`.  A 1-game batch underneath."""
+
+    def __init__(self, id=None, settings=None, init_env=None, _lib_path=None):
+        self.id = id
+        src = init_env._vec if isinstance(init_env, tetris_environment) else init_env
+        self._vec = tetris_environment_vector(1, type(self), init_envs=src, settings=settings, _lib_path=_lib_path)
+        self.settings = self._vec.settings
+        self.player_idxs = self._vec.player_idxs
+        self.state_processor = self._vec.state_processor
+
+    @property
+    def done(self):
+        return bool(self._vec.done[0])
+
+    @property
+    def backend(self):
+        return self._vec.backend
+
+    def reset(self):
+        self._vec.reset()
+
+    def get_state(self):
+        return self._vec.get_state()[0]
+
+    def set(self, e):
+        if isinstance(e, tetris_environment):
+            e = e._vec
+        self._vec.set(e if isinstance(e, tetris_environment_vector) else [e])
+
+    def copy(self):
+        return tetris_environment(settings=self.settings, init_env=self, _lib_path=self._vec._lib_path)
+
+    def get_actions(self, state, player=None):
+        assert type(player) is int, f"tetris_environment.get_actions(int player) was called with type(player)={type(player)}"
+        self.set(state)                               # tetris_environment.py:80
+        return self._vec.get_actions(player=player)[0]
+
+    def get_random_action(self, player=None):
+        return self._vec.get_random_action(player=player)[0]
+
+    def simulate_actions(self, actions, player=None, finalize=True):
+        assert type(actions) is action_list, f"simulate_actions was called with type(actions)={type(actions)}"
+        return self._vec.simulate_actions([actions], player=player, finalize=finalize)[0]
+
+    def simulate_all_actions(self, state, player=None, finalize=True):
+        return self.simulate_actions(self.get_actions(state, player=player), player=player, finalize=finalize)
+
+    def perform_action(self, action, player=None, simulate=False, finalize=True):
+        assert type(player) is int, f"tetris_environment.perform_action(action a,int p) was called with type(player)={type(player)}"
+        if finalize and not simulate:
+            r, d = self._vec.perform_action([action], player=player)
+            return r[0], d[0]
+        keys, lens = self._vec._pack([action], [player], 1)      # simulate=True: no reward bookkeeping (tetris_environment.py:109-116)
+        if finalize:
+            done, _, _ = self._vec.backend.step_keys(keys, lens, ms=self.settings["time_elapsed_each_action"])
+            self._vec.done[0] = bool(done[0])
+        else:
+            self._vec.backend.make_actions(keys, lens)
+        return None, self.done
+
+    def get_winner(self):
+        return self._vec.get_winner()[0]
+
+    def get_info(self):
+        return self._vec.get_info()[0]
+
+    def get_fields(self):
+        return self._vec.get_fields()[0]
+
+    def render(self):
+        return None
+
+    def generate_pieces(self):
+        return self._vec.generate_pieces()[0]
+
+    def __str__(self):
+        width = max(len(k) for k in self.settings)
+        return "tetris_environment settings:\n" + "".join("\t{:{}}\t{}\n".format(k, width, v) for k, v in self.settings.items())

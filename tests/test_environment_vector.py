@@ -186,3 +186,37 @@ def test_get_actions_simulate_all_and_random_action(kind):
         ref.make_actions(keys, lens); ref.finish_actions(400)
     a, b = env.backend.observe()[0], ref.observe()[0]
     assert np.array_equal(a["field"] > 0, b["field"] > 0) and np.array_equal(a["next"], b["next"])
+
+
+@pytest.mark.parametrize("kind", engines.ENGINE_PARAMS)
+def test_single_env_sandbox_api(kind):
+    """The single-game class agents use as a sandbox (tetris_environment.py:11-227; sherlock_utils.py:13-20)."""
+    env_mod = __import__("importlib").import_module("drl-tetris_amd.environment")
+    edt = __import__("importlib").import_module("drl-tetris_amd.data_types")
+    lib = ge.build_harness() if kind == "harness" else None
+    settings = {"n_players": 2, "game_size": [20, 10], "seed_source": _Clock(700)}
+    env = env_mod.tetris_environment(settings=settings, _lib_path=lib)
+    sandbox = env_mod.tetris_environment(settings=settings, _lib_path=lib)
+    ref = orc.OracleBatch(1, 2, 20, 10, seeds=701)
+    ref.reset(seeds=702)
+    np.random.seed(3)
+    for it in range(10):
+        p = it % 2
+        state = env.get_state()
+        actions = sandbox.get_actions(state, player=p)                       # sets the sandbox to `state`, enumerates
+        assert [list(a) for a in actions] == [list(a) for a in edt.action_list(ref.get_actions(0, p), remove_null=True)]
+        future = sandbox.simulate_all_actions(state, player=p, finalize=False)
+        assert len(future) == len(actions)
+        a = actions[np.random.randint(len(actions))]
+        reward, done = env.perform_action(a, player=p)
+        keys = np.zeros((1, 2, 48), np.uint8); lens = np.ones((1, 2), np.uint8)
+        keys[0, p, : len(a)] = a; lens[0, p] = len(a)
+        ref.make_actions(keys, lens)
+        assert bool(ref.finish_actions(400)[0]) == done and float(reward()) in (-1.0, 0.0, 1.0)
+    got, want = env.get_state().backend_state.states, ref.observe()[0][0]
+    for p in range(2):
+        assert np.array_equal(got[p].field > 0, want[p]["field"][:20] > 0) and int(got[p].nextpiece[0]) == int(want[p]["next"])
+    twin = env.copy()
+    twin.perform_action(edt.action([7]), player=0)
+    assert not np.array_equal(twin.backend.snapshot(), env.backend.snapshot())
+    assert env.get_winner() is None and "game_size" in str(env)
