@@ -25,14 +25,19 @@ __device__ const ShapeTable d_shape_table = make_shape_table();
 
 template <int P, int MODE, bool TINT>
 __global__ __launch_bounds__(256) void k_game(KArgs a) {
-    __shared__ __attribute__((aligned(16))) uint32_t s_shapes[32];
+    // Shape table in LDS, one private 128-byte copy per wave: no workgroup barrier, so a wave starts computing as soon as
+    // the state words it needs first have arrived instead of waiting for all loads of all four waves.  The table load is
+    // issued before the state loads (loads return in order), and ds_write -> ds_read order within a wave is by lgkmcnt.
+    __shared__ __attribute__((aligned(16))) uint32_t s_shapes_all[4][32];
+    uint32_t* s_shapes = s_shapes_all[threadIdx.x >> 6];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool active = i < a.n;
     LaneCounters cnt = {0, 0, 0, 0};                   // (per-lane sums feed the CPU test harness only)
+    const uint32_t shape_word = d_shape_table.s[threadIdx.x & 31];
     Game<P> g;
-    if (active) game_load<P, MODE, TINT>(a, i, g);          // state loads in flight ...
-    if (threadIdx.x < 32) s_shapes[threadIdx.x] = d_shape_table.s[threadIdx.x];
-    __syncthreads();                                   // ... while the shape table lands in LDS
+    if (active) game_load<P, MODE, TINT>(a, i, g);
+    if ((threadIdx.x & 63) < 32) s_shapes[threadIdx.x & 31] = shape_word;
+    __builtin_amdgcn_wave_barrier();
     if (active) game_run<P, MODE, TINT>(a, i, s_shapes, g, cnt);
 }
 
@@ -60,7 +65,9 @@ __global__ __launch_bounds__(256) void k_totals(const uint32_t* gstate, int n_ga
 // backup for the rollback when player 0 died), B0 / B1 = delayCheck of player 0, then player 1, C = winner logic.
 template <int MODE>
 __global__ __launch_bounds__(256) void k_duo(KArgs a) {
-    __shared__ __attribute__((aligned(16))) uint32_t s_shapes[32];
+    __shared__ __attribute__((aligned(16))) uint32_t s_shapes_all[4][32];      // per-wave copy, no block barrier (see k_game)
+    uint32_t* s_shapes = s_shapes_all[threadIdx.x >> 6];
+    const uint32_t shape_word = d_shape_table.s[threadIdx.x & 31];
     const int lane = threadIdx.x & 63, side = lane >> 5;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int gi = wave * 32 + (lane & 31);
@@ -72,8 +79,8 @@ __global__ __launch_bounds__(256) void k_duo(KArgs a) {
         load_game_words<1>(a.gstate, N, (size_t)gi, g);
         load_player(a.state + (size_t)side * N + gi, 2 * N, q, false);
     }
-    if (threadIdx.x < 32) s_shapes[threadIdx.x] = d_shape_table.s[threadIdx.x];
-    __syncthreads();
+    if (lane < 32) s_shapes[lane] = shape_word;
+    __builtin_amdgcn_wave_barrier();
     Ctx cx = make_ctx(a, s_shapes, false);
     uint32_t my_lines = 0, my_sent = 0;
     int done = 0;
@@ -154,9 +161,10 @@ __global__ __launch_bounds__(256) void k_duo(KArgs a) {
 
 template <int STAGE, bool TINT>
 __global__ __launch_bounds__(256) void k_split(KArgs a) {
-    __shared__ __attribute__((aligned(16))) uint32_t s_shapes[32];
-    if (threadIdx.x < 32) s_shapes[threadIdx.x] = d_shape_table.s[threadIdx.x];
-    __syncthreads();
+    __shared__ __attribute__((aligned(16))) uint32_t s_shapes_all[4][32];      // per-wave copy, no block barrier (see k_game)
+    uint32_t* s_shapes = s_shapes_all[threadIdx.x >> 6];
+    if ((threadIdx.x & 63) < 32) s_shapes[threadIdx.x & 31] = d_shape_table.s[threadIdx.x & 31];
+    __builtin_amdgcn_wave_barrier();
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < a.n) split_body<STAGE, TINT>(a, i, s_shapes);
 }
