@@ -50,6 +50,16 @@ TE_HD void st_stream(uint32_t* p, uint32_t v) { if (TE_ST_NT) __builtin_nontempo
 TE_HD uint32_t ld_stream(const uint32_t* p) { return *p; }
 TE_HD void st_stream(uint32_t* p, uint32_t v) { *p = v; }
 #endif
+
+// State word `word_off` (in words, uniform across the wave) of the board at byte offset `o` (per lane, < 4 GiB) of a
+// uniform base: on the GPU the base + word offset stay in SGPRs and the lane offset is the 32-bit VGPR offset of the
+// global_load/store, so the ~60 state accesses of a step need no per-lane 64-bit address arithmetic.
+TE_HD uint32_t ldw(const uint32_t* base, uint32_t o, size_t word_off) {
+    return ld_stream((const uint32_t*)((const char*)(base + word_off) + o));
+}
+TE_HD void stw(uint32_t* base, uint32_t o, size_t word_off, uint32_t v) {
+    st_stream((uint32_t*)((char*)(base + word_off) + o), v);
+}
 TE_HD int imin(int a, int b) { return a < b ? a : b; }
 TE_HD int imax(int a, int b) { return a > b ? a : b; }
 TE_HD uint32_t f2u(float f) { union { float f; uint32_t u; } v; v.f = f; return v.u; }
@@ -146,61 +156,62 @@ struct Game {
 // ---------------------------------------------------------------- load / store (SoA, coalesced)
 // state[(w * P + p) * n + slot]; game words at gstate[w * n + slot]
 // one player-board: word w of this board lives at s[w * ws]
-TE_HD void load_player(const uint32_t* s, size_t ws, Player& q, bool tint, bool queue = true) {
-    for (int c = 0; c < NCOL; c++) q.col[c] = ld_stream(&s[(size_t)(W_COL0 + c) * ws]);
+TE_HD void load_player(const uint32_t* s, uint32_t o, size_t ws, Player& q, bool tint, bool queue = true) {
+    for (int c = 0; c < NCOL; c++) q.col[c] = ldw(s, o, (size_t)(W_COL0 + c) * ws);
     if (tint)
         for (int k = 0; k < 3; k++)
-            for (int c = 0; c < NCOL; c++) q.tint[k][c] = ld_stream(&s[(size_t)(W_TINT0 + 10 * k + c) * ws]);
-    uint32_t w = ld_stream(&s[(size_t)W_PIECE * ws]);
+            for (int c = 0; c < NCOL; c++) q.tint[k][c] = ldw(s, o, (size_t)(W_TINT0 + 10 * k + c) * ws);
+    uint32_t w = ldw(s, o, (size_t)W_PIECE * ws);
     q.kind = w & 7; q.rot = (w >> 3) & 3; q.x = (int)((w >> 5) & 15) - 4; q.y = (w >> 9) & 31;
     q.next = (w >> 14) & 7; q.dead = (w >> 17) & 1; q.lock_armed = (w >> 18) & 1; q.reward = (w >> 19) & 255;
-    w = ld_stream(&s[(size_t)W_MISC * ws]);
+    w = ldw(s, o, (size_t)W_MISC * ws);
     q.inc_count = w & 255; q.combo_count = (w >> 8) & 255; q.line_count = (w >> 16) & 255;
     q.qlen = (w >> 24) & 15; q.q_overflow = (w >> 28) & 1;
     if (!queue) { q.inc_count = 0; q.qlen = 0; q.q_overflow = 0; }      // invariants of a game without opponents
-    q.time_ms = (int32_t)ld_stream(&s[(size_t)W_TIME * ws]);
-    w = ld_stream(&s[(size_t)W_DROPCOMBO * ws]);
+    q.time_ms = (int32_t)ldw(s, o, (size_t)W_TIME * ws);
+    w = ldw(s, o, (size_t)W_DROPCOMBO * ws);
     q.drop_delay = w & 0xFFFF; q.combo_remaining = w >> 16;
-    q.drop_time = (int32_t)ld_stream(&s[(size_t)W_DROP_TIME * ws]);
-    q.speedup_time = (int32_t)ld_stream(&s[(size_t)W_SPEEDUP_TIME * ws]);
-    q.lock_time = (int32_t)ld_stream(&s[(size_t)W_LOCK_TIME * ws]);
-    q.combo_start = (int32_t)ld_stream(&s[(size_t)W_COMBO_START * ws]);
-    q.combo_time = (int32_t)ld_stream(&s[(size_t)W_COMBO_TIME * ws]);
+    q.drop_time = (int32_t)ldw(s, o, (size_t)W_DROP_TIME * ws);
+    q.speedup_time = (int32_t)ldw(s, o, (size_t)W_SPEEDUP_TIME * ws);
+    q.lock_time = (int32_t)ldw(s, o, (size_t)W_LOCK_TIME * ws);
+    q.combo_start = (int32_t)ldw(s, o, (size_t)W_COMBO_START * ws);
+    q.combo_time = (int32_t)ldw(s, o, (size_t)W_COMBO_TIME * ws);
     // nobody can send garbage to a single player: incoming lines, hole draws and the queue timer never leave their
     // reset values (0, 0, 1000), so 1-player kernels neither load nor (for the two zeros) store these words
-    q.incoming = queue ? u2f(ld_stream(&s[(size_t)W_INCOMING * ws])) : 0.0f;
-    q.min_remaining = queue ? (int32_t)ld_stream(&s[(size_t)W_MIN_REMAINING * ws]) : 1000;
-    q.piece_draws = ld_stream(&s[(size_t)W_PIECE_DRAWS * ws]);
-    q.hole_draws = queue ? ld_stream(&s[(size_t)W_HOLE_DRAWS * ws]) : 0u;
-    q.pgroup = ld_stream(&s[(size_t)W_PIECE_GROUP * ws]);
-    w = ld_stream(&s[(size_t)W_STATS0 * ws]); q.lines_sent = w & 0xFFFF; q.lines_cleared = w >> 16;
-    w = ld_stream(&s[(size_t)W_STATS1 * ws]); q.lines_blocked = w & 0xFFFF; q.max_combo = w >> 16;
-    w = ld_stream(&s[(size_t)W_STATS2 * ws]); q.lines_seen = w & 0xFFFF; q.garbage_cleared = w >> 16;
+    q.incoming = queue ? u2f(ldw(s, o, (size_t)W_INCOMING * ws)) : 0.0f;
+    q.min_remaining = queue ? (int32_t)ldw(s, o, (size_t)W_MIN_REMAINING * ws) : 1000;
+    q.piece_draws = ldw(s, o, (size_t)W_PIECE_DRAWS * ws);
+    q.hole_draws = queue ? ldw(s, o, (size_t)W_HOLE_DRAWS * ws) : 0u;
+    q.pgroup = ldw(s, o, (size_t)W_PIECE_GROUP * ws);
+    w = ldw(s, o, (size_t)W_STATS0 * ws); q.lines_sent = w & 0xFFFF; q.lines_cleared = w >> 16;
+    w = ldw(s, o, (size_t)W_STATS1 * ws); q.lines_blocked = w & 0xFFFF; q.max_combo = w >> 16;
+    w = ldw(s, o, (size_t)W_STATS2 * ws); q.lines_seen = w & 0xFFFF; q.garbage_cleared = w >> 16;
     q.q_loaded = queue && q.qlen > 0;
     q.pf_ok = 0; q.pf_raw.lo = 0; q.pf_raw.hi = 0;
     if (queue)
         for (int i = 0; i < FIFO_CAP; i++) { q.qcount[i] = 0; q.qdelay[i] = 0; }
     if (q.q_loaded) {
         for (int i = 0; i < FIFO_CAP / 2; i++) {
-            uint32_t cw = ld_stream(&s[(size_t)(W_FIFO_COUNT0 + i) * ws]);
+            uint32_t cw = ldw(s, o, (size_t)(W_FIFO_COUNT0 + i) * ws);
             q.qcount[2 * i] = (int16_t)(cw & 0xFFFF);
             q.qcount[2 * i + 1] = (int16_t)(cw >> 16);
         }
-        for (int i = 0; i < FIFO_CAP; i++) q.qdelay[i] = (int32_t)ld_stream(&s[(size_t)(W_FIFO_DELAY0 + i) * ws]);
+        for (int i = 0; i < FIFO_CAP; i++) q.qdelay[i] = (int32_t)ldw(s, o, (size_t)(W_FIFO_DELAY0 + i) * ws);
     }
 }
 
 // the per-game words
 template <int P>
 TE_HD void load_game_words(const uint32_t* gstate, size_t n, size_t slot, Game<P>& g) {
-    uint32_t meta = ld_stream(&gstate[(size_t)G_META * n + slot]);
+    const uint32_t o = (uint32_t)slot * 4u;
+    uint32_t meta = ldw(gstate, o, (size_t)G_META * n);
     g.seed16 = meta & 0xFFFFu;
     g.round_over = (meta >> 16) & 1;
     g.last_winner = (int)((meta >> 17) & 0xF) - 1;
     g.flags = (meta >> 21) & 7u;
-    g.episode = ld_stream(&gstate[(size_t)G_EPISODE * n + slot]);
-    g.roll_lines = ld_stream(&gstate[(size_t)G_LINES * n + slot]);
-    g.roll_sent = ld_stream(&gstate[(size_t)G_SENT * n + slot]);
+    g.episode = ldw(gstate, o, (size_t)G_EPISODE * n);
+    g.roll_lines = ldw(gstate, o, (size_t)G_LINES * n);
+    g.roll_sent = ldw(gstate, o, (size_t)G_SENT * n);
     g.status = 0;
 }
 
@@ -208,54 +219,55 @@ template <int P>
 TE_HD void load_game(const uint32_t* state, const uint32_t* gstate, size_t n, size_t slot, Game<P>& g, bool tint = false, bool queue = true) {
     load_game_words<P>(gstate, n, slot, g);
     TE_UNROLL
-    for (int p = 0; p < P; p++) load_player(state + (size_t)p * n + slot, (size_t)P * n, g.pl[p], tint, queue);
+    for (int p = 0; p < P; p++) load_player(state + (size_t)p * n, (uint32_t)slot * 4u, (size_t)P * n, g.pl[p], tint, queue);
 }
 
-TE_HD void store_player(uint32_t* s, size_t ws, const Player& q, bool tint, bool queue = true) {
-    for (int c = 0; c < NCOL; c++) st_stream(&s[(size_t)(W_COL0 + c) * ws], q.col[c]);
+TE_HD void store_player(uint32_t* s, uint32_t o, size_t ws, const Player& q, bool tint, bool queue = true) {
+    for (int c = 0; c < NCOL; c++) stw(s, o, (size_t)(W_COL0 + c) * ws, q.col[c]);
     if (tint)
         for (int k = 0; k < 3; k++)
-            for (int c = 0; c < NCOL; c++) st_stream(&s[(size_t)(W_TINT0 + 10 * k + c) * ws], q.tint[k][c]);
-    st_stream(&s[(size_t)W_PIECE * ws], (uint32_t)q.kind | ((uint32_t)q.rot << 3) | ((uint32_t)(q.x + 4) << 5) | ((uint32_t)q.y << 9) |
+            for (int c = 0; c < NCOL; c++) stw(s, o, (size_t)(W_TINT0 + 10 * k + c) * ws, q.tint[k][c]);
+    stw(s, o, (size_t)W_PIECE * ws, (uint32_t)q.kind | ((uint32_t)q.rot << 3) | ((uint32_t)(q.x + 4) << 5) | ((uint32_t)q.y << 9) |
                               ((uint32_t)q.next << 14) | ((uint32_t)q.dead << 17) | ((uint32_t)q.lock_armed << 18) |
                               ((uint32_t)(q.reward & 255) << 19));
-    st_stream(&s[(size_t)W_MISC * ws], (uint32_t)(q.inc_count & 255) | ((uint32_t)(q.combo_count & 255) << 8) |
+    stw(s, o, (size_t)W_MISC * ws, (uint32_t)(q.inc_count & 255) | ((uint32_t)(q.combo_count & 255) << 8) |
                              ((uint32_t)(q.line_count & 255) << 16) | ((uint32_t)q.qlen << 24) | ((uint32_t)q.q_overflow << 28));
-    st_stream(&s[(size_t)W_TIME * ws], (uint32_t)q.time_ms);
-    st_stream(&s[(size_t)W_DROPCOMBO * ws], ((uint32_t)q.drop_delay & 0xFFFF) | (q.combo_remaining << 16));
-    st_stream(&s[(size_t)W_DROP_TIME * ws], (uint32_t)q.drop_time);
-    st_stream(&s[(size_t)W_SPEEDUP_TIME * ws], (uint32_t)q.speedup_time);
-    st_stream(&s[(size_t)W_LOCK_TIME * ws], (uint32_t)q.lock_time);
-    st_stream(&s[(size_t)W_COMBO_START * ws], (uint32_t)q.combo_start);
-    st_stream(&s[(size_t)W_COMBO_TIME * ws], (uint32_t)q.combo_time);
-    if (queue) st_stream(&s[(size_t)W_INCOMING * ws], f2u(q.incoming));
-    st_stream(&s[(size_t)W_MIN_REMAINING * ws], (uint32_t)q.min_remaining);
-    st_stream(&s[(size_t)W_PIECE_DRAWS * ws], q.piece_draws);
-    if (queue) st_stream(&s[(size_t)W_HOLE_DRAWS * ws], q.hole_draws);
-    st_stream(&s[(size_t)W_PIECE_GROUP * ws], q.pgroup);
-    st_stream(&s[(size_t)W_STATS0 * ws], (q.lines_sent & 0xFFFF) | (q.lines_cleared << 16));
-    st_stream(&s[(size_t)W_STATS1 * ws], (q.lines_blocked & 0xFFFF) | (q.max_combo << 16));
-    st_stream(&s[(size_t)W_STATS2 * ws], (q.lines_seen & 0xFFFF) | (q.garbage_cleared << 16));
+    stw(s, o, (size_t)W_TIME * ws, (uint32_t)q.time_ms);
+    stw(s, o, (size_t)W_DROPCOMBO * ws, ((uint32_t)q.drop_delay & 0xFFFF) | (q.combo_remaining << 16));
+    stw(s, o, (size_t)W_DROP_TIME * ws, (uint32_t)q.drop_time);
+    stw(s, o, (size_t)W_SPEEDUP_TIME * ws, (uint32_t)q.speedup_time);
+    stw(s, o, (size_t)W_LOCK_TIME * ws, (uint32_t)q.lock_time);
+    stw(s, o, (size_t)W_COMBO_START * ws, (uint32_t)q.combo_start);
+    stw(s, o, (size_t)W_COMBO_TIME * ws, (uint32_t)q.combo_time);
+    if (queue) stw(s, o, (size_t)W_INCOMING * ws, f2u(q.incoming));
+    stw(s, o, (size_t)W_MIN_REMAINING * ws, (uint32_t)q.min_remaining);
+    stw(s, o, (size_t)W_PIECE_DRAWS * ws, q.piece_draws);
+    if (queue) stw(s, o, (size_t)W_HOLE_DRAWS * ws, q.hole_draws);
+    stw(s, o, (size_t)W_PIECE_GROUP * ws, q.pgroup);
+    stw(s, o, (size_t)W_STATS0 * ws, (q.lines_sent & 0xFFFF) | (q.lines_cleared << 16));
+    stw(s, o, (size_t)W_STATS1 * ws, (q.lines_blocked & 0xFFFF) | (q.max_combo << 16));
+    stw(s, o, (size_t)W_STATS2 * ws, (q.lines_seen & 0xFFFF) | (q.garbage_cleared << 16));
     if (queue && (q.q_loaded || q.qlen > 0)) {
         for (int i = 0; i < FIFO_CAP / 2; i++)
-            st_stream(&s[(size_t)(W_FIFO_COUNT0 + i) * ws], ((uint32_t)q.qcount[2 * i] & 0xFFFF) | ((uint32_t)q.qcount[2 * i + 1] << 16));
-        for (int i = 0; i < FIFO_CAP; i++) st_stream(&s[(size_t)(W_FIFO_DELAY0 + i) * ws], (uint32_t)q.qdelay[i]);
+            stw(s, o, (size_t)(W_FIFO_COUNT0 + i) * ws, ((uint32_t)q.qcount[2 * i] & 0xFFFF) | ((uint32_t)q.qcount[2 * i + 1] << 16));
+        for (int i = 0; i < FIFO_CAP; i++) stw(s, o, (size_t)(W_FIFO_DELAY0 + i) * ws, (uint32_t)q.qdelay[i]);
     }
 }
 
 template <int P>
 TE_HD void store_game_words(uint32_t* gstate, size_t n, size_t slot, const Game<P>& g) {
-    st_stream(&gstate[(size_t)G_META * n + slot], g.seed16 | ((uint32_t)g.round_over << 16) | ((uint32_t)(g.last_winner + 1) << 17) | (g.flags << 21));
-    st_stream(&gstate[(size_t)G_EPISODE * n + slot], g.episode);
-    st_stream(&gstate[(size_t)G_LINES * n + slot], g.roll_lines);
-    st_stream(&gstate[(size_t)G_SENT * n + slot], g.roll_sent);
+    const uint32_t o = (uint32_t)slot * 4u;
+    stw(gstate, o, (size_t)G_META * n, g.seed16 | ((uint32_t)g.round_over << 16) | ((uint32_t)(g.last_winner + 1) << 17) | (g.flags << 21));
+    stw(gstate, o, (size_t)G_EPISODE * n, g.episode);
+    stw(gstate, o, (size_t)G_LINES * n, g.roll_lines);
+    stw(gstate, o, (size_t)G_SENT * n, g.roll_sent);
 }
 
 template <int P>
 TE_HD void store_game(uint32_t* state, uint32_t* gstate, size_t n, size_t slot, const Game<P>& g, bool tint = false, bool queue = true) {
     store_game_words<P>(gstate, n, slot, g);
     TE_UNROLL
-    for (int p = 0; p < P; p++) store_player(state + (size_t)p * n + slot, (size_t)P * n, g.pl[p], tint, queue);
+    for (int p = 0; p < P; p++) store_player(state + (size_t)p * n, (uint32_t)slot * 4u, (size_t)P * n, g.pl[p], tint, queue);
 }
 
 // ---------------------------------------------------------------- board primitives

@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void k_duo(KArgs a) {
     Player& q = g.pl[0];
     if (active) {
         load_game_words<1>(a.gstate, N, (size_t)gi, g);
-        load_player(a.state + (size_t)side * N + gi, 2 * N, q, false);
+        load_player(a.state, (uint32_t)(side * a.n_games + gi) * 4u, 2 * N, q, false);
     }
     if (lane < 32) s_shapes[lane] = shape_word;
     __builtin_amdgcn_wave_barrier();
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void k_duo(KArgs a) {
     }
     const uint32_t opp_lines = __shfl_xor(my_lines, 32), opp_sent = __shfl_xor(my_sent, 32);
     if (active) {
-        store_player(a.state + (size_t)side * N + gi, 2 * N, q, false);
+        store_player(a.state, (uint32_t)(side * a.n_games + gi) * 4u, 2 * N, q, false);
         if (MODE == M_STEP_RT) {
             if (a.lines) a.lines[(size_t)side * a.n + gi] = (uint8_t)q.reward;
             if (a.dead) a.dead[(size_t)side * a.n + gi] = (uint8_t)q.dead;
@@ -538,6 +538,8 @@ static int create_impl(tetris_batch** out, int n_games, int n_players, int heigh
     *out = nullptr;
     if (n_games < 1) return fail(TETRIS_E_ARG, "n_games must be >= 1");
     if (n_players != 1 && n_players != 2) return fail(TETRIS_E_ARG, "n_players must be 1 or 2");
+    if ((long long)n_games * n_players > (1ll << 30))       // one row of a state word stays below 4 GiB (32-bit lane offsets)
+        return fail(TETRIS_E_ARG, "n_games * n_players must be <= 2^30");
     if (height < 4 || height > MAX_H) return fail(TETRIS_E_ARG, "height must be in [4, 31]");
     if (width != NCOL) return fail(TETRIS_E_ARG, "width must be 10 (the reference hard-codes 10, gamePlay.cpp:202)");
     if (!piece_map) return fail(TETRIS_E_ARG, "piece_map is NULL");
