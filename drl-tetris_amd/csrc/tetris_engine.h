@@ -51,6 +51,27 @@ TE_HD uint32_t ld_stream(const uint32_t* p) { return *p; }
 TE_HD void st_stream(uint32_t* p, uint32_t v) { *p = v; }
 #endif
 
+// Diagnostic build only (-DTE_PHASE_TRACE, profiles/phase_trace.py): the first active lane of a wave writes the shader
+// clock at phase boundaries into a device buffer.  Product builds compile TE_STAMP to nothing.
+#if defined(TE_PHASE_TRACE) && defined(__HIPCC__)
+__device__ unsigned long long d_trace[2048 * 16];
+#endif
+#if defined(TE_PHASE_TRACE) && defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ void te_stamp(int k, bool realtime = false) {
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned long long t = realtime ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime();
+    const unsigned wv = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int first = __ffsll((unsigned long long)__ballot(1)) - 1;
+    if ((int)(threadIdx.x & 63) == first && wv < 2048) d_trace[wv * 16 + k] = t;
+    __builtin_amdgcn_sched_barrier(0);
+}
+#define TE_STAMP(k) te_stamp(k)
+#define TE_STAMP_RT(k) te_stamp(k, true)
+#else
+#define TE_STAMP(k) do {} while (0)
+#define TE_STAMP_RT(k) do {} while (0)
+#endif
+
 // State word `word_off` (in words, uniform across the wave) of the board at byte offset `o` (per lane, < 4 GiB) of a
 // uniform base: on the GPU the base + word offset stay in SGPRs and the lane offset is the 32-bit VGPR offset of the
 // global_load/store, so the ~60 state accesses of a step need no per-lane 64-bit address arithmetic.
@@ -93,12 +114,29 @@ constexpr uint32_t make_shape(int kind, int rot) {
         if ((nibs >> (4 * gx)) & 0xF) { if (gx < minc) minc = gx; if (gx > maxc) maxc = gx; }
     return nibs | ((uint32_t)minc << 16) | ((uint32_t)maxc << 18);
 }
-struct ShapeTable { uint32_t s[32]; };
+// hard-drop word of a shape (see drop_distance_bytes): byte gx = 0x40 - (lowest cell row of piece column gx + 1), or 0x7F
+// for an empty piece column
+constexpr uint32_t make_drop_word(uint32_t nibs) {
+    uint32_t w = 0;
+    for (int gx = 0; gx < 4; gx++) {
+        uint32_t n = (nibs >> (4 * gx)) & 0xF;
+        int bottom = -1;
+        for (int gy = 0; gy < 4; gy++)
+            if ((n >> gy) & 1) bottom = gy;
+        w |= (uint32_t)(bottom < 0 ? 0x7F : 0x40 - (bottom + 1)) << (8 * gx);
+    }
+    return w;
+}
+constexpr int SHAPE_WORDS = 64;                     // [0,32) shape words, [32,64) hard-drop words, index (kind << 2) | rot
+struct ShapeTable { uint32_t s[SHAPE_WORDS]; };
 constexpr ShapeTable make_shape_table() {
     ShapeTable t{};
     for (int k = 0; k < 7; k++)
-        for (int r = 0; r < 4; r++) t.s[k * 4 + r] = make_shape(k, r);
-    for (int r = 0; r < 4; r++) t.s[28 + r] = 0;   // kind 7 = "no piece" (gameField.cpp:147-151)
+        for (int r = 0; r < 4; r++) {
+            t.s[k * 4 + r] = make_shape(k, r);
+            t.s[32 + k * 4 + r] = make_drop_word(t.s[k * 4 + r] & 0xFFFFu);
+        }
+    for (int r = 0; r < 4; r++) { t.s[28 + r] = 0; t.s[60 + r] = 0x7F7F7F7Fu; }   // kind 7 = "no piece" (gameField.cpp:147-151)
     return t;
 }
 constexpr ShapeTable SHAPES = make_shape_table();
@@ -151,6 +189,7 @@ struct Game {
     uint32_t episode;
     uint32_t roll_lines, roll_sent;  // cumulative rollout counters (G_LINES, G_SENT)
     uint32_t status;                 // te::Status bits raised while stepping this game
+    uint32_t draw0, draw1;           // rollout kernels: the synthetic policy's words for the NEXT step (registers only)
 };
 
 // ---------------------------------------------------------------- load / store (SoA, coalesced)
@@ -325,6 +364,35 @@ TE_HD int drop_distance(const Ctx& cx, const Player& q, uint32_t shape) {
 }
 
 // gameField.cpp:105-110 addPiece: the four squares become occupied and take the piece's tile value (kind + 1)
+// The same distance for a piece that FITS at (x, y), from byte arithmetic: depth[c] = rows from y down to the first
+// occupied square (or the floor) of board column c, for the 10 columns held in registers; the four depths under the piece
+// are four consecutive bytes of the 16-byte strip [wall wall c0..c9 wall wall wall wall] (one v_alignbyte after a word
+// select); adding the shape's hard-drop word (make_drop_word) gives 0x40 + distance per occupied piece column and >= 0x7F
+// for empty ones.  A byte below 0x40 means a square above that piece column's top cell inside the 4x4 box (an overhang
+// entered by a kick): those lanes take the exact routine.
+TE_HD int drop_distance_bytes(const Ctx& cx, const Player& q, uint32_t shape, uint32_t drop_word) {
+    uint32_t d[NCOL];
+    for (int c = 0; c < NCOL; c++) d[c] = (uint32_t)ctz32((q.col[c] | cx.floor_bits) >> q.y);     // y <= H: never zero
+    const uint32_t w0 = (d[0] << 16) | (d[1] << 24);
+    const uint32_t w1 = d[2] | (d[3] << 8) | (d[4] << 16) | (d[5] << 24);
+    const uint32_t w2 = d[6] | (d[7] << 8) | (d[8] << 16) | (d[9] << 24);
+    const unsigned xs = (unsigned)(q.x + 2);           // 0..12 for a piece that fits
+    const bool hi2 = (xs & 8u) != 0, hi1 = (xs & 4u) != 0;
+    const uint32_t lo = hi2 ? (hi1 ? 0u : w2) : (hi1 ? w1 : w0);
+    const uint32_t hi = hi2 ? 0u : (hi1 ? w2 : w1);
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t under = __builtin_amdgcn_alignbyte(hi, lo, xs & 3u);
+#else
+    const uint32_t under = (uint32_t)((((uint64_t)hi << 32) | lo) >> (8 * (xs & 3u)));
+#endif
+    const uint32_t sum = under + drop_word;            // bytes <= 32 + 0x7F: no carries between bytes
+    const uint32_t b0 = sum & 0xFFu, b1 = (sum >> 8) & 0xFFu, b2 = (sum >> 16) & 0xFFu, b3 = sum >> 24;
+    const uint32_t m01 = b0 < b1 ? b0 : b1, m23 = b2 < b3 ? b2 : b3;
+    const uint32_t m = m01 < m23 ? m01 : m23;
+    if (m - 0x40u > 0x3Eu) return drop_distance(cx, q, shape);      // overhang (m < 0x40) or no piece at all (m >= 0x7F)
+    return (int)(m - 0x40u);
+}
+
 TE_HD void stamp(const Ctx& cx, Player& q, uint32_t shape) {
     unsigned xs = (unsigned)(q.x + 2);
     if (xs > 12u) return;
@@ -763,6 +831,16 @@ TE_HD Shapes4 shapes_of_kind(const Ctx& cx, int kind) {
 #endif
     return out;
 }
+TE_HD Shapes4 drop_words_of_kind(const Ctx& cx, int kind) {
+    Shapes4 out;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint4 v = *reinterpret_cast<const uint4*>(cx.shapes + 32 + ((kind & 7) << 2));
+    out.r[0] = v.x; out.r[1] = v.y; out.r[2] = v.z; out.r[3] = v.w;
+#else
+    for (int i = 0; i < 4; i++) out.r[i] = cx.shapes[32 + (((kind & 7) << 2) | i)];
+#endif
+    return out;
+}
 TE_HD uint32_t pick4(const Shapes4& s, int rot) {
     uint32_t lo = (rot & 1) ? s.r[1] : s.r[0];
     uint32_t hi = (rot & 1) ? s.r[3] : s.r[2];
@@ -770,6 +848,26 @@ TE_HD uint32_t pick4(const Shapes4& s, int rot) {
 }
 
 // bit xs of the result = 1  <=>  the shape fits at x = xs - 2 (xs = 0..12) in this band window
+// the same map from 32-bit tests: positions 0..4 against band nibbles 0..7, 5..8 against nibbles 4..11, 9..12 against 8..15
+TE_HD uint32_t free_positions32(uint64_t band, uint32_t shape) {
+    const uint32_t lo = (uint32_t)band, hi = (uint32_t)(band >> 32), mid = (lo >> 16) | (hi << 16);
+    const uint32_t s0 = shape & 0xFFFFu, s1 = s0 << 4, s2 = s0 << 8, s3 = s0 << 12, s4 = s0 << 16;
+    uint32_t free = 0;
+    free |= (s0 & lo) == 0 ? 1u << 0 : 0u;
+    free |= (s1 & lo) == 0 ? 1u << 1 : 0u;
+    free |= (s2 & lo) == 0 ? 1u << 2 : 0u;
+    free |= (s3 & lo) == 0 ? 1u << 3 : 0u;
+    free |= (s4 & lo) == 0 ? 1u << 4 : 0u;
+    free |= (s1 & mid) == 0 ? 1u << 5 : 0u;
+    free |= (s2 & mid) == 0 ? 1u << 6 : 0u;
+    free |= (s3 & mid) == 0 ? 1u << 7 : 0u;
+    free |= (s4 & mid) == 0 ? 1u << 8 : 0u;
+    free |= (s1 & hi) == 0 ? 1u << 9 : 0u;
+    free |= (s2 & hi) == 0 ? 1u << 10 : 0u;
+    free |= (s3 & hi) == 0 ? 1u << 11 : 0u;
+    free |= (s4 & hi) == 0 ? 1u << 12 : 0u;
+    return free;
+}
 TE_HD uint32_t free_positions(uint64_t band, uint32_t shape) {
     const uint64_t pc = (uint64_t)(shape & 0xFFFFu);
     uint32_t free = 0;
@@ -784,37 +882,90 @@ TE_HD uint32_t free_positions(uint64_t band, uint32_t shape) {
 //  * key 2 then t x key 3: with the set F of free x positions at this height, "left until blocked"
 //    ends just right of the nearest blocked position on the left, and each of the t single steps right
 //    succeeds until the first blocked position on the right (a blocked step stays blocked).
+// 32 bits (8 nibbles) of a band window starting at nibble position p, -8 <= p <= 16; positions outside the band read
+// as wall.  A shape (16 bits) shifted by 4k, k = 0..4, tested against it is the collision test at band position p + k:
+// one funnel shift per window, then and + compare per test, and out-of-range positions collide with the walls by
+// construction (every shape has a cell in its first three and in its last three columns).
+TE_HD uint32_t band_win32(uint64_t band, int p) {
+    const int off = 4 * p + 32;                      // bit offset into [~0, lo, hi, ~0]
+    const uint32_t lo = (uint32_t)band, hi = (uint32_t)(band >> 32);
+    const int k = off >> 5;
+    const uint32_t a = k == 0 ? ~0u : (k == 1 ? lo : (k == 2 ? hi : ~0u));
+    const uint32_t b = k == 0 ? lo : (k == 1 ? hi : ~0u);
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_alignbit(b, a, (uint32_t)off & 31u);
+#else
+    const int sh = off & 31;
+    return sh ? (a >> sh) | (b << (32 - sh)) : a;
+#endif
+}
+
 TE_HD void play_rt(const Ctx& cx, Player& q, int r, int t) {
 #if defined(TE_ABLATE) && (TE_ABLATE & 2)
     lock_piece(cx, q); return;                       // diagnostic build: no rotations / slides
 #endif
     const Shapes4 sh = shapes_of_kind(cx, q.kind);
+    const Shapes4 dw = drop_words_of_kind(cx, q.kind);
     uint64_t band = band_window(cx, q, q.y);
-    bool fit1 = fits_band(band, pick4(sh, q.rot + 1), q.x);
-    bool fit2 = fits_band(band, pick4(sh, q.rot + 2), q.x);
-    bool fit3 = fits_band(band, pick4(sh, q.rot + 3), q.x);
-    bool easy = (r < 1 || fit1) && (r < 2 || fit2) && (r < 3 || fit3);
+    uint32_t win = band_win32(band, q.x);            // band positions x .. x+4 (piece x - 2 .. x + 2), piece itself at k = 2
+    const bool fit1 = (((pick4(sh, q.rot + 1) & 0xFFFFu) << 8) & win) == 0;
+    const bool fit2 = (((pick4(sh, q.rot + 2) & 0xFFFFu) << 8) & win) == 0;
+    const bool fit3 = (((pick4(sh, q.rot + 3) & 0xFFFFu) << 8) & win) == 0;
+    const bool easy = (r < 1 || fit1) && (r < 2 || fit2) && (r < 3 || fit3);
+    TE_STAMP(10);
     if (easy) {
         q.rot = (q.rot + r) & 3;
     } else {
-        uint64_t b1 = 0;
-        bool b1_ok = false;
-        for (int i = 0; i < 3; i++)
-            if (i < r) {
-                const int nr = (q.rot + 1) & 3;
-                rotate_shape_band(cx, q, nr, pick4(sh, nr), band, b1, b1_ok);
+        // Some rotation needs the kick table (gameField.cpp:55-103).  One loop iteration per KICK, not per rotation: the
+        // rotations that fit in place around it are taken from no-kick tests at the current position, so a wave normally
+        // runs this body once (it runs for the whole wave as soon as one lane needs it).
+        int adv = fit1 ? (fit2 ? (fit3 ? 3 : 2) : 1) : 0;      // leading rotations that fit in place (adv < r here)
+        q.rot = (q.rot + adv) & 3;
+        int left = r - adv;
+        while (left > 0) {
+            const int nr = (q.rot + 1) & 3;
+            const uint32_t s1 = pick4(sh, nr) & 0xFFFFu;        // does not fit at (x, y): the 7 offsets in the reference's order
+            const uint64_t b1 = band_window(cx, q, q.y + 1);
+            const uint32_t win1 = band_win32(b1, q.x);
+            const uint32_t sA = s1, sB = s1 << 4, sC = s1 << 8, sD = s1 << 12, sE = s1 << 16;   // dx = -2 .. +2
+            // all seven tests, then a priority select (no nested divergent branches)
+            const bool k0 = (sC & win1) == 0, k1 = (sB & win) == 0, k2 = (sD & win) == 0;
+            const bool k3 = (sB & win1) == 0, k4 = (sD & win1) == 0;
+            const bool k5 = (sA & win) == 0, k6 = (sE & win) == 0;
+            int dx = k6 ? 2 : 99, dy = 0;
+            dx = k5 ? -2 : dx;
+            if (k4) { dx = 1; dy = 1; }
+            if (k3) { dx = -1; dy = 1; }
+            if (k2) { dx = 1; dy = 0; }
+            if (k1) { dx = -1; dy = 0; }
+            if (k0) { dx = 0; dy = 1; }
+            if (dx == 99) break;                                // nothing fits: every further press fails the same way
+            q.rot = nr; q.x += dx; q.y += dy;
+            if (dy) band = b1;
+            left--;
+            if (left > 0) {                                     // rotations that fit in place at the new position
+                win = band_win32(band, q.x);
+                const bool g1 = (((pick4(sh, q.rot + 1) & 0xFFFFu) << 8) & win) == 0;
+                const bool g2 = left > 1 && (((pick4(sh, q.rot + 2) & 0xFFFFu) << 8) & win) == 0;
+                const int more = g1 ? (g2 ? 2 : 1) : 0;
+                q.rot = (q.rot + more) & 3;
+                left -= more;
             }
+        }
     }
+    TE_STAMP(11);
     const uint32_t shape = pick4(sh, q.rot);
-    const uint32_t free = free_positions(band, shape);
+    const uint32_t free = free_positions32(band, shape);
     const int xs0 = q.x + 2;
     const uint32_t blocked_left = ~free & ((1u << xs0) - 1u);
     int xs = blocked_left ? 32 - clz32(blocked_left) : 0;
     const uint32_t blocked_right = (~free >> (xs + 1)) | (1u << 13);
     xs += imin(t, ctz32(blocked_right));
     q.x = xs - 2;
+    TE_STAMP(12);
     // gamePlay.cpp:48-52 hd_make
-    q.y += drop_distance(cx, q, shape);
+    q.y += drop_distance_bytes(cx, q, shape, pick4(dw, q.rot));
+    TE_STAMP(13);
     stamp(cx, q, shape);
     q.drop_time = q.time_ms;
     q.lock_armed = 0;
@@ -1076,6 +1227,7 @@ TE_HD int finish_game(const Ctx& cx, Game<P>& g, int ms) {
         if (sent == -1) { q.dead = 1; stop = true; continue; }     // the reference breaks out of loop 1
         if (sent) share_lines<P>(g, p, sent);
     }
+    TE_STAMP(6);
     int alive = 0;
     TE_UNROLL
     for (int p = 0; p < P; p++) {
@@ -1166,6 +1318,7 @@ TE_HD uint32_t episode_seed(uint32_t game, uint32_t episode) { return (12345u + 
 // Philox4x32-10 (Salmon et al., SC'11), key (k0, 0), counter (c0, c1, c2, 0): the synthetic policy
 TE_HD void philox4x32_10(uint32_t k0, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t out[4]) {
     uint32_t k1 = 0u, c3 = 0u;
+    TE_UNROLL                                        // straight-line: lets the scheduler run it under outstanding loads
     for (int r = 0; r < 10; r++) {
         uint64_t p0 = (uint64_t)0xD2511F53u * c0;
         uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;

@@ -28,17 +28,29 @@ __global__ __launch_bounds__(256) void k_game(KArgs a) {
     // Shape table in LDS, one private 128-byte copy per wave: no workgroup barrier, so a wave starts computing as soon as
     // the state words it needs first have arrived instead of waiting for all loads of all four waves.  The table load is
     // issued before the state loads (loads return in order), and ds_write -> ds_read order within a wave is by lgkmcnt.
-    __shared__ __attribute__((aligned(16))) uint32_t s_shapes_all[4][32];
+    __shared__ __attribute__((aligned(16))) uint32_t s_shapes_all[4][SHAPE_WORDS];
     uint32_t* s_shapes = s_shapes_all[threadIdx.x >> 6];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool active = i < a.n;
     LaneCounters cnt = {0, 0, 0, 0};                   // (per-lane sums feed the CPU test harness only)
-    const uint32_t shape_word = d_shape_table.s[threadIdx.x & 31];
+    TE_STAMP(0); TE_STAMP_RT(1);
+    const uint32_t shape_word = d_shape_table.s[threadIdx.x & 63];
     Game<P> g;
     if (active) game_load<P, MODE, TINT>(a, i, g);
-    if ((threadIdx.x & 63) < 32) s_shapes[threadIdx.x & 31] = shape_word;
+    TE_STAMP(2);
+#if defined(TE_PHASE_TRACE) && TE_PHASE_TRACE == 2
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // variant: time until ALL state words have arrived
+    TE_STAMP(3);
+#endif
+    s_shapes[threadIdx.x & 63] = shape_word;
     __builtin_amdgcn_wave_barrier();
     if (active) game_run<P, MODE, TINT>(a, i, s_shapes, g, cnt);
+    TE_STAMP(9);
+#if defined(TE_PHASE_TRACE) && TE_PHASE_TRACE == 3
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // variant: time until all stores are acknowledged
+    TE_STAMP(10);
+#endif
+    TE_STAMP(14); TE_STAMP_RT(15);
 }
 
 // Sums the per-game cumulative rollout counters (G_EPISODE, G_LINES, G_SENT): run once before and once
@@ -65,9 +77,9 @@ __global__ __launch_bounds__(256) void k_totals(const uint32_t* gstate, int n_ga
 // backup for the rollback when player 0 died), B0 / B1 = delayCheck of player 0, then player 1, C = winner logic.
 template <int MODE>
 __global__ __launch_bounds__(256) void k_duo(KArgs a) {
-    __shared__ __attribute__((aligned(16))) uint32_t s_shapes_all[4][32];      // per-wave copy, no block barrier (see k_game)
+    __shared__ __attribute__((aligned(16))) uint32_t s_shapes_all[4][SHAPE_WORDS];      // per-wave copy, no block barrier (see k_game)
     uint32_t* s_shapes = s_shapes_all[threadIdx.x >> 6];
-    const uint32_t shape_word = d_shape_table.s[threadIdx.x & 31];
+    const uint32_t shape_word = d_shape_table.s[threadIdx.x & 63];
     const int lane = threadIdx.x & 63, side = lane >> 5;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int gi = wave * 32 + (lane & 31);
@@ -79,7 +91,7 @@ __global__ __launch_bounds__(256) void k_duo(KArgs a) {
         load_game_words<1>(a.gstate, N, (size_t)gi, g);
         load_player(a.state, (uint32_t)(side * a.n_games + gi) * 4u, 2 * N, q, false);
     }
-    if (lane < 32) s_shapes[lane] = shape_word;
+    s_shapes[lane] = shape_word;
     __builtin_amdgcn_wave_barrier();
     Ctx cx = make_ctx(a, s_shapes, false);
     uint32_t my_lines = 0, my_sent = 0;
@@ -161,9 +173,9 @@ __global__ __launch_bounds__(256) void k_duo(KArgs a) {
 
 template <int STAGE, bool TINT>
 __global__ __launch_bounds__(256) void k_split(KArgs a) {
-    __shared__ __attribute__((aligned(16))) uint32_t s_shapes_all[4][32];      // per-wave copy, no block barrier (see k_game)
+    __shared__ __attribute__((aligned(16))) uint32_t s_shapes_all[4][SHAPE_WORDS];      // per-wave copy, no block barrier (see k_game)
     uint32_t* s_shapes = s_shapes_all[threadIdx.x >> 6];
-    if ((threadIdx.x & 63) < 32) s_shapes[threadIdx.x & 31] = d_shape_table.s[threadIdx.x & 31];
+    s_shapes[threadIdx.x & 63] = d_shape_table.s[threadIdx.x & 63];
     __builtin_amdgcn_wave_barrier();
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < a.n) split_body<STAGE, TINT>(a, i, s_shapes);
@@ -501,6 +513,15 @@ static int stage_in(tetris_batch* b, Stage& s, const void* src, size_t bytes) {
 extern "C" {
 
 const char* tetris_last_error(void) { return g_err.c_str(); }
+
+#if defined(TE_PHASE_TRACE)
+// diagnostic build only: copies the phase stamps out (and clears them)
+extern "C" int tetris_debug_trace(unsigned long long* out, int n_words) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(d_trace), (size_t)n_words * 8) != hipSuccess) return -1;
+    static unsigned long long zero[2048 * 16];
+    return hipMemcpyToSymbol(HIP_SYMBOL(d_trace), zero, sizeof zero) == hipSuccess ? 0 : -1;
+}
+#endif
 
 int tetris_device_count(void) {
     int n = 0;

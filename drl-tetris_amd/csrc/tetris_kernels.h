@@ -96,10 +96,23 @@ TE_HD void make_rt(const Ctx& cx, Game<P>& g, int player, int r, int t) {
 
 // Phase 1 of a lane's work: issue the state loads (nothing here needs the LDS shape table, so the
 // kernel runs this BEFORE its table-init barrier and both memory round-trips overlap).
+// SURVEY.md §8(d) synthetic policy: words 0 and 1 of Philox4x32-10 keyed by (policy_seed, global game id, step)
+TE_HD void policy_draw(const KArgs& a, uint32_t slot, unsigned long long step, uint32_t& w0, uint32_t& w1) {
+#if defined(TE_ABLATE) && (TE_ABLATE & 1)
+    w0 = slot + (uint32_t)step; w1 = slot * 7u + (uint32_t)step;      // diagnostic build: no Philox
+#else
+    uint32_t w[4];
+    philox4x32_10(a.policy_seed, a.game_offset + slot, (uint32_t)step, (uint32_t)(step >> 32), w);
+    w0 = w[0]; w1 = w[1];
+#endif
+}
+
 template <int P, int MODE, bool TINT = false>
 TE_HD void game_load(const KArgs& a, int i, Game<P>& g) {
     const size_t slot = a.idx ? (size_t)a.idx[i] : (size_t)i;
     if (MODE != M_INIT && MODE != M_SPLIT_INIT) load_game<P>(a.state, a.gstate, (size_t)a.n_games, slot, g, TINT, P > 1 || MODE == M_SPLIT_RESET);   // split batches: 1-player layout WITH a queue
+    // the first step's draw depends on kernel arguments only: its 40 dependent multiplies run while the state loads are in flight
+    if (MODE == M_ROLLOUT) policy_draw(a, (uint32_t)slot, a.first_step, g.draw0, g.draw1);
 }
 
 // Phase 2: step and store.
@@ -143,19 +156,16 @@ TE_HD void game_run(const KArgs& a, int i, const uint32_t* shapes, Game<P>& g, L
             for (int p = 0; p < P; p++) prefetch_next(cx, g.pl[p], g.seed16, g.status);
             ResetPrefetch rpf;
             prefetch_reset(cx, episode_seed(a.game_offset + (uint32_t)slot, g.episode + 1), rpf);
-            uint32_t w[4];
-#if defined(TE_ABLATE) && (TE_ABLATE & 1)
-            w[0] = (uint32_t)slot + (uint32_t)step; w[1] = (uint32_t)slot * 7u + (uint32_t)step;   // diagnostic build: no Philox
-#else
-            philox4x32_10(a.policy_seed, a.game_offset + (uint32_t)slot, (uint32_t)step, (uint32_t)(step >> 32), w);
-#endif
-            int r = (int)(w[0] & 3u), t = (int)(w[1] % 10u);
+            int r = (int)(g.draw0 & 3u), t = (int)(g.draw1 % 10u);
             int player = P > 1 ? (int)(step % (unsigned long long)P) : 0;
+            TE_STAMP(4);
             uint32_t sent_before = 0;
             TE_UNROLL
             for (int p = 0; p < P; p++) sent_before += g.pl[p].lines_sent;
             make_rt<P>(cx, g, player, r, t);
+            TE_STAMP(5);
             int done = finish_game<P>(cx, g, a.ms);
+            TE_STAMP(7);
             cnt.steps++;
             uint32_t sent_after = 0;
             TE_UNROLL
@@ -173,6 +183,8 @@ TE_HD void game_run(const KArgs& a, int i, const uint32_t* shapes, Game<P>& g, L
                 g.episode++;
                 reset_game<P>(cx, g, episode_seed(a.game_offset + (uint32_t)slot, g.episode), &rpf);
             }
+            if (s + 1 < a.steps) policy_draw(a, (uint32_t)slot, step + 1, g.draw0, g.draw1);
+            TE_STAMP(8);
         }
     }
     store_game<P>(a.state, a.gstate, N, slot, g, TINT, P > 1 || MODE == M_SPLIT_INIT || MODE == M_SPLIT_RESET);   // 1-player: FIFO words stay as zeroed at creation
