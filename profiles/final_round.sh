@@ -2,6 +2,7 @@
 # Everything the round's numbers come from, in one GPU call: parity suite, smoke, the bench line (with CPU baseline), the
 # 2-player / fused variants, the rocprofv3 kernel-trace summary of the same bench command, PMC traffic passes.
 set -x
+set -e -o pipefail      # a failed or timed-out GPU step ends the call: no further GPU step is started after it
 mkdir -p gpurun_out/final
 timeout -k 10 400 python -m pytest tests -m gpu -q > gpurun_out/final/pytest_gpu.log 2>&1; tail -1 gpurun_out/final/pytest_gpu.log
 timeout -k 10 200 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/final/smoke.log 2>&1; tail -1 gpurun_out/final/smoke.log
