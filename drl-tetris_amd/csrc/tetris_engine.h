@@ -72,6 +72,16 @@ __device__ __forceinline__ void te_stamp(int k, bool realtime = false) {
 #define TE_STAMP_RT(k) do {} while (0)
 #endif
 
+// Test-only path counters (tests/cpu_harness defines TE_PATH_COUNTERS): how often the rare branches of the key interpreter
+// ran, so the parity tests can assert that they reached them.  Nothing in device or product builds.
+#if defined(TE_PATH_COUNTERS) && !defined(__HIPCC__)
+enum PathCounter { PC_KICK = 0, PC_KICK_2ND, PC_KICK_3RD, PC_KICK_FAILED, PC_KICK_DOWN, PC_DROP_EXACT, PC_RT_OFF_SPAWN, PC_NCOUNTERS };
+extern unsigned long long te_path_count[PC_NCOUNTERS];
+#define TE_COUNT(i) (te_path_count[i]++)
+#else
+#define TE_COUNT(i) do {} while (0)
+#endif
+
 // State word `word_off` (in words, uniform across the wave) of the board at byte offset `o` (per lane, < 4 GiB) of a
 // uniform base: on the GPU the base + word offset stay in SGPRs and the lane offset is the 32-bit VGPR offset of the
 // global_load/store, so the ~60 state accesses of a step need no per-lane 64-bit address arithmetic.
@@ -389,7 +399,7 @@ TE_HD int drop_distance_bytes(const Ctx& cx, const Player& q, uint32_t shape, ui
     const uint32_t b0 = sum & 0xFFu, b1 = (sum >> 8) & 0xFFu, b2 = (sum >> 16) & 0xFFu, b3 = sum >> 24;
     const uint32_t m01 = b0 < b1 ? b0 : b1, m23 = b2 < b3 ? b2 : b3;
     const uint32_t m = m01 < m23 ? m01 : m23;
-    if (m - 0x40u > 0x3Eu) return drop_distance(cx, q, shape);      // overhang (m < 0x40) or no piece at all (m >= 0x7F)
+    if (m - 0x40u > 0x3Eu) { TE_COUNT(PC_DROP_EXACT); return drop_distance(cx, q, shape); }      // overhang (m < 0x40) or no piece at all (m >= 0x7F)
     return (int)(m - 0x40u);
 }
 
@@ -906,6 +916,7 @@ TE_HD void play_rt(const Ctx& cx, Player& q, int r, int t) {
 #endif
     const Shapes4 sh = shapes_of_kind(cx, q.kind);
     const Shapes4 dw = drop_words_of_kind(cx, q.kind);
+    if (q.y != 0 || q.x != (NCOL - 4) / 2) TE_COUNT(PC_RT_OFF_SPAWN);
     uint64_t band = band_window(cx, q, q.y);
     uint32_t win = band_win32(band, q.x);            // band positions x .. x+4 (piece x - 2 .. x + 2), piece itself at k = 2
     const bool fit1 = (((pick4(sh, q.rot + 1) & 0xFFFFu) << 8) & win) == 0;
@@ -922,6 +933,8 @@ TE_HD void play_rt(const Ctx& cx, Player& q, int r, int t) {
         int adv = fit1 ? (fit2 ? (fit3 ? 3 : 2) : 1) : 0;      // leading rotations that fit in place (adv < r here)
         q.rot = (q.rot + adv) & 3;
         int left = r - adv;
+        int kicks = 0;
+        (void)kicks;
         while (left > 0) {
             const int nr = (q.rot + 1) & 3;
             const uint32_t s1 = pick4(sh, nr) & 0xFFFFu;        // does not fit at (x, y): the 7 offsets in the reference's order
@@ -939,7 +952,10 @@ TE_HD void play_rt(const Ctx& cx, Player& q, int r, int t) {
             if (k2) { dx = 1; dy = 0; }
             if (k1) { dx = -1; dy = 0; }
             if (k0) { dx = 0; dy = 1; }
-            if (dx == 99) break;                                // nothing fits: every further press fails the same way
+            if (dx == 99) { TE_COUNT(PC_KICK_FAILED); break; }  // nothing fits: every further press fails the same way
+            kicks++;
+            TE_COUNT(kicks == 1 ? PC_KICK : (kicks == 2 ? PC_KICK_2ND : PC_KICK_3RD));
+            if (dy) TE_COUNT(PC_KICK_DOWN);
             q.rot = nr; q.x += dx; q.y += dy;
             if (dy) band = b1;
             left--;

@@ -14,7 +14,10 @@
 #include <string>
 #include <vector>
 
+#define TE_PATH_COUNTERS 1
 #include "../../drl-tetris_amd/csrc/tetris_kernels.h"
+
+unsigned long long te::te_path_count[te::PC_NCOUNTERS];
 
 using namespace te;
 
@@ -406,6 +409,11 @@ int tetris_rollout_random(tetris_batch* b, int launches, int steps_per_launch, u
     b->margin = saved;
     if (elapsed_ms) *elapsed_ms = 0.0f;
     return rc;
+}
+
+// test-only: reads (and clears) the key-interpreter path counters of tetris_engine.h
+void harness_path_counts(unsigned long long* out) {
+    for (int i = 0; i < PC_NCOUNTERS; i++) { out[i] = te_path_count[i]; te_path_count[i] = 0; }
 }
 
 }  // extern "C"

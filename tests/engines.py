@@ -44,3 +44,16 @@ def assert_same_state(eng, ref, idx=None, where=""):
             raise AssertionError(f"{where}: '{f}' differs for {len(bad)} boards; first game {g} player {p}:\n got  {a[f][g, p]}\n want {b[f][g, p]}")
     assert np.array_equal(ro_a, ro_b), f"{where}: round_over"
     assert np.array_equal(lw_a, lw_b), f"{where}: last_winner"
+
+
+PATH_COUNTERS = ["kick", "kick_2nd", "kick_3rd", "kick_failed", "kick_down", "drop_exact", "rt_off_spawn"]
+
+
+def harness_path_counts():
+    """Key-interpreter path counters of the CPU harness build since the last call (test-only; tetris_engine.h TE_COUNT).
+    Not thread-safe: meaningful for single-threaded harness calls, which is how the harness runs."""
+    import ctypes as C
+    lib = C.CDLL(ge.build_harness())
+    out = (C.c_ulonglong * len(PATH_COUNTERS))()
+    lib.harness_path_counts(out)
+    return dict(zip(PATH_COUNTERS, [int(v) for v in out]))

@@ -47,6 +47,52 @@ def test_step_rt_with_resets(kind, P, H):
 
 
 @pytest.mark.parametrize("kind", engines.ENGINE_PARAMS)
+@pytest.mark.parametrize("P,H", [(1, 20), (2, 20), (1, 9), (1, 30)])
+def test_rt_from_arbitrary_positions(kind, P, H):
+    """(r, t) actions applied to pieces that are NOT at their spawn position: steps of arbitrary keys without a hard
+    drop (slides, soft drops, rotations with kicks; gravity and lock-down move the piece meanwhile) leave pieces mid-air,
+    next to walls and under overhangs of messy stacks; the following step_rt must rotate with the reference's kick order,
+    slide and hard-drop from there (gameField.cpp:10-103, gamePlay.cpp:48-52).  Exercises the kick loop with several kicks
+    per action and the exact hard-drop routine behind the byte-parallel one."""
+    n = 2048 if kind == "hip" else 256
+    K = 12
+    eng, ref = _pair(kind, n, P, H, seed_base=4000)
+    if kind == "harness":
+        engines.harness_path_counts()              # clear
+    rng = np.random.default_rng(100 * P + H)
+    episode = np.zeros(n, np.int64)
+    for s in range(140):
+        if s % 3 != 2:
+            # keys 1..6 and 8..10 only: no hard drop, so the piece stays in play wherever the keys and the timers leave it
+            pool = np.array([1, 2, 3, 4, 5, 6, 6, 6, 8, 9, 10], np.uint8)
+            lens = rng.integers(0, K, (n, P)).astype(np.uint8)
+            keys = pool[rng.integers(0, len(pool), (n, P, K))]
+            done, _, _ = eng.step_keys(keys, lens)
+            ref.make_actions(keys, lens)
+            d2 = ref.finish_actions(400)
+        else:
+            rot = rng.integers(0, 4, n).astype(np.uint8)
+            trans = rng.integers(0, 10, n).astype(np.uint8)
+            player = rng.integers(0, P, n).astype(np.uint8)
+            done, _, _ = eng.step_rt(rot, trans, player, full=True)
+            d2 = ref.step_rt(rot, trans, player)
+        assert np.array_equal(done, d2), f"done differs at step {s}"
+        if s % 12 == 11:
+            engines.assert_same_state(eng, ref, where=f"step {s}")
+        idx = np.nonzero(d2)[0].astype(np.int32)
+        if len(idx):
+            episode[idx] += 1
+            sd = orc.episode_seed(idx + 4000, episode[idx])
+            eng.reset(idx, sd)
+            ref.reset(idx, sd)
+    engines.assert_same_state(eng, ref, where="end")
+    if kind == "harness":                          # the run really reached the rare paths it is here for
+        counts = engines.harness_path_counts()
+        for name in ("rt_off_spawn", "kick", "kick_2nd", "kick_failed", "kick_down", "drop_exact"):
+            assert counts[name] > 0, (name, counts)
+
+
+@pytest.mark.parametrize("kind", engines.ENGINE_PARAMS)
 @pytest.mark.parametrize("P", [1, 2])
 def test_random_key_sequences(kind, P):
     """General key interpreter (PythonHandle.cpp:73-112): every key 0..10, soft drops, keys after a lock,
