@@ -90,6 +90,7 @@ __global__ __launch_bounds__(256) void k_duo(KArgs a) {
     if (active) {
         load_game_words<1>(a.gstate, N, (size_t)gi, g);
         load_player(a.state, (uint32_t)(side * a.n_games + gi) * 4u, 2 * N, q, false);
+        if (MODE == M_ROLLOUT) policy_draw(a, (uint32_t)gi, a.first_step, g.draw0, g.draw1);   // under the loads (see game_load)
     }
     s_shapes[lane] = shape_word;
     __builtin_amdgcn_wave_barrier();
@@ -107,9 +108,7 @@ __global__ __launch_bounds__(256) void k_duo(KArgs a) {
         if (active) {
             if (MODE == M_ROLLOUT) {
                 const unsigned long long step = a.first_step + (unsigned long long)s;
-                uint32_t w[4];
-                philox4x32_10(a.policy_seed, a.game_offset + (uint32_t)gi, (uint32_t)step, (uint32_t)(step >> 32), w);
-                r = (int)(w[0] & 3u); t = (int)(w[1] % 10u); acting = (int)(step % 2ull);
+                r = (int)(g.draw0 & 3u); t = (int)(g.draw1 % 10u); acting = (int)(step % 2ull);
                 prefetch_reset(cx, episode_seed(a.game_offset + (uint32_t)gi, g.episode + 1), rpf);
             } else {
                 r = a.rot[gi] & 3; t = a.trans[gi]; acting = a.player ? a.player[gi] : 0;
@@ -149,6 +148,7 @@ __global__ __launch_bounds__(256) void k_duo(KArgs a) {
                     g.episode++;
                     reset_split(cx, g, episode_seed(a.game_offset + (uint32_t)gi, g.episode));
                 }
+                if (s + 1 < n_steps) policy_draw(a, (uint32_t)gi, a.first_step + (unsigned long long)s + 1ull, g.draw0, g.draw1);
             }
         }
     }
