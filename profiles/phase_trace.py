@@ -54,4 +54,12 @@ for rep in range(3):
     for a, c in zip(keys[:-1], keys[1:]):
         d = (t[:, c] - t[:, a]) / cyc_per_us
         print(f"  {NAMES[a]:36s} -> {NAMES[c]:36s} median {np.median(d):5.2f} us  p10 {np.percentile(d, 10):5.2f}  p90 {np.percentile(d, 90):5.2f}")
+    # the launch ends with its slowest wave: what did the last finishers spend their time on?
+    order = np.argsort(end_us)[::-1][:6]
+    print("  slowest waves (wave id: start, end us; then per-phase us in the order above):")
+    for w in order:
+        ph = " ".join(f"{(t[w, c] - t[w, a]) / cyc_per_us:4.2f}" for a, c in zip(keys[:-1], keys[1:]))
+        print(f"   wave {w:4d}: {start_us[w]:4.2f} {end_us[w]:4.2f} | {ph}")
+    med = " ".join(f"{np.median((t[:, c] - t[:, a]) / cyc_per_us):4.2f}" for a, c in zip(keys[:-1], keys[1:]))
+    print(f"   median wave          | {med}")
 b.close()
