@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256) void k_observe(const uint32_t* state, const ui
 // in LDS; after a barrier the workgroup streams its 256 boards' planes out as ONE contiguous run of dwords, so the
 // uint8 rows leave the chip fully coalesced (a lane writing its own 200 bytes would not be).
 template <int P>
-__global__ __launch_bounds__(256) void k_observe_packed(const uint32_t* state, int n_games, int n, const int32_t* idx,
+__global__ __launch_bounds__(256) void k_observe_packed_bytes(const uint32_t* state, int n_games, int n, const int32_t* idx,
                                                         const uint8_t* player, int H, uint8_t* visual, uint8_t* vector,
                                                         uint8_t* piece) {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_cells[];      // 256 * H * 10 bytes
@@ -245,12 +245,67 @@ __global__ __launch_bounds__(256) void k_observe_packed(const uint32_t* state, i
     }
 }
 
+// Even heights (H * 10 cells = a whole number of words per board, the usual 20 / 22 rows): the byte planes are built as
+// words in registers — two rows = 20 cells = 5 words per loop trip, columns indexed statically — and go to LDS as dwords
+// with a row stride of nw + 1 words (odd: conflict-free), instead of 200 byte writes per lane; the workgroup's tile then
+// leaves as coalesced dword stores.  The 12 vector bytes of a board leave as 3 dwords.
+template <int P, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_observe_packed(const uint32_t* state, int n_games, int n, const int32_t* idx,
+                                                          const uint8_t* player, int H, uint8_t* visual, uint8_t* vector,
+                                                          uint8_t* piece, uint32_t inv_nw) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_words[];      // BLOCK * (nw + 1) words
+    const int nw = H * NCOL / 4, pitch = nw + 1;
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    const int first = blockIdx.x * BLOCK;
+    const int nb = (n - first < BLOCK) ? n - first : BLOCK;
+    for (int sl = 0; sl < P; sl++) {
+        if (i < n) {
+            const size_t slot = idx ? (size_t)idx[i] : (size_t)i;
+            const int me = player ? player[i] : 0;
+            const int p = (sl == 0) ? me : (P - 1 - me);
+            const size_t ws = (size_t)P * n_games;
+            const uint32_t* s = state + (size_t)p * n_games + slot;
+            uint32_t col[NCOL];
+            for (int c = 0; c < NCOL; c++) col[c] = s[(size_t)(W_COL0 + c) * ws];
+            const uint32_t w = s[(size_t)W_PIECE * ws], m = s[(size_t)W_MISC * ws], dc = s[(size_t)W_DROPCOMBO * ws];
+            uint32_t* row = s_words + (size_t)threadIdx.x * pitch;
+            for (int yp = 0; yp < H / 2; yp++) {
+                uint32_t lo[NCOL], hi[NCOL];                 // cells of rows 2 yp and 2 yp + 1
+                for (int c = 0; c < NCOL; c++) { lo[c] = col[c] & 1u; hi[c] = (col[c] >> 1) & 1u; col[c] >>= 2; }
+                row[5 * yp + 0] = lo[0] | (lo[1] << 8) | (lo[2] << 16) | (lo[3] << 24);
+                row[5 * yp + 1] = lo[4] | (lo[5] << 8) | (lo[6] << 16) | (lo[7] << 24);
+                row[5 * yp + 2] = lo[8] | (lo[9] << 8) | (hi[0] << 16) | (hi[1] << 24);
+                row[5 * yp + 3] = hi[2] | (hi[3] << 8) | (hi[4] << 16) | (hi[5] << 24);
+                row[5 * yp + 4] = hi[6] | (hi[7] << 8) | (hi[8] << 16) | (hi[9] << 24);
+            }
+            // state_processors.py:23-54 vector: x, y, incoming, combo time, combo count, one-hot next piece
+            const uint32_t x = (uint32_t)((int)((w >> 5) & 15) - 4) & 0xFFu, y = (w >> 9) & 31u, next = (w >> 14) & 7u;
+            uint32_t t = ((dc >> 16) + 50u) & 0xFFFFu;     // uint16 + 50 wraps like numpy (state_processors.py:38)
+            if (t > 25000u) t = 25000u;
+            uint32_t* v = (uint32_t*)(vector + ((size_t)sl * n + i) * 12);
+            const uint64_t hot = next < 7u ? (1ull << (8 * next)) : 0ull;          // bytes 5..11
+            v[0] = x | (y << 8) | ((m & 255u) << 16) | ((t / 100u) << 24);
+            v[1] = ((m >> 8) & 255u) | ((uint32_t)(hot & 0xFFFFFFu) << 8);
+            v[2] = (uint32_t)(hot >> 24);
+            piece[(size_t)sl * n + i] = (uint8_t)(w & 7u);
+        }
+        __syncthreads();
+        uint32_t* dst = (uint32_t*)(visual + ((size_t)sl * n + first) * (size_t)(H * NCOL));
+        const uint32_t words = (uint32_t)nb * (uint32_t)nw;
+        for (uint32_t g = threadIdx.x; g < words; g += BLOCK) {
+            const uint32_t t = __umulhi(g, inv_nw);          // g / nw (exact: g < 2^16, inv_nw = ceil(2^32 / nw))
+            dst[g] = s_words[g + t];
+        }
+        __syncthreads();
+    }
+}
+
 template <int P>
 __global__ __launch_bounds__(256) void k_enumerate(const uint32_t* state, int n_games, int n, const int32_t* idx,
                                                    const uint8_t* player, int H, uint8_t* valid, int8_t* land_y,
                                                    uint8_t* cleared, uint32_t* after) {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < (size_t)n * 40) enumerate_body<P>(state, n_games, t, idx, player, H, d_shape_table.s, valid, land_y, cleared, after);
+    if (t < (size_t)n * 40) enumerate_body<P>(state, n_games, t, idx, player, H, d_shape_table.s, valid, land_y, cleared, after, t);
 }
 
 template <int P>
@@ -902,16 +957,32 @@ int tetris_observe_packed_dev(tetris_batch* b, const int32_t* d_idx, int n, cons
     if (n < 0 || (!d_idx && n > b->N)) return fail(TETRIS_E_ARG, "n out of range");
     if (n == 0) return TETRIS_OK;
     dim3 grid((unsigned)((n + 255) / 256)), block(256);
-    const size_t lds = (size_t)256 * b->H * NCOL;
+    if (b->H % 2 == 0 && ((uintptr_t)d_visual & 3u) == 0 && ((uintptr_t)d_vector & 3u) == 0) {
+        // one wave per workgroup (<= 20 KB of LDS): several workgroups per CU overlap their load / build / store phases
+        constexpr int OB = 64;
+        const int nw = b->H * NCOL / 4;
+        const size_t lds = (size_t)OB * (nw + 1) * 4;
+        const uint32_t inv_nw = (uint32_t)(((1ull << 32) + (uint64_t)nw - 1) / (uint64_t)nw);
+        dim3 ogrid((unsigned)((n + OB - 1) / OB)), oblock(OB);
+        if (b->P == 1)
+            hipLaunchKernelGGL((k_observe_packed<1, OB>), ogrid, oblock, lds, b->stream, b->d_state, b->N, n, d_idx, d_player, b->H,
+                               d_visual, d_vector, d_piece, inv_nw);
+        else
+            hipLaunchKernelGGL((k_observe_packed<2, OB>), ogrid, oblock, lds, b->stream, b->d_state, b->N, n, d_idx, d_player, b->H,
+                               d_visual, d_vector, d_piece, inv_nw);
+        HIP_TRY(hipGetLastError());
+        return TETRIS_OK;
+    }
+    const size_t lds = (size_t)256 * b->H * NCOL;             // odd heights (boards are not word-aligned in `visual`): byte tile
     if (lds > 48 * 1024) {      // up to 79 KB of the CU's 160 KB for 31-row boards
-        const void* fn = b->P == 1 ? (const void*)k_observe_packed<1> : (const void*)k_observe_packed<2>;
+        const void* fn = b->P == 1 ? (const void*)k_observe_packed_bytes<1> : (const void*)k_observe_packed_bytes<2>;
         HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
     if (b->P == 1)
-        hipLaunchKernelGGL(k_observe_packed<1>, grid, block, lds, b->stream, b->d_state, b->N, n, d_idx, d_player, b->H, d_visual,
+        hipLaunchKernelGGL(k_observe_packed_bytes<1>, grid, block, lds, b->stream, b->d_state, b->N, n, d_idx, d_player, b->H, d_visual,
                            d_vector, d_piece);
     else
-        hipLaunchKernelGGL(k_observe_packed<2>, grid, block, lds, b->stream, b->d_state, b->N, n, d_idx, d_player, b->H, d_visual,
+        hipLaunchKernelGGL(k_observe_packed_bytes<2>, grid, block, lds, b->stream, b->d_state, b->N, n, d_idx, d_player, b->H, d_visual,
                            d_vector, d_piece);
     HIP_TRY(hipGetLastError());
     return TETRIS_OK;

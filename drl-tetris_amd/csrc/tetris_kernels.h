@@ -353,8 +353,9 @@ TE_HD int observe_board(const uint32_t* state, int n_games, size_t slot, int P, 
 
 // TestField.cpp:64-125 (drop placements): lane t = (game i, rotation r, column index xi)
 template <int P>
+// `after_row`: row of `after` ([row][10] words) this placement writes
 TE_HD void enumerate_body(const uint32_t* state, int n_games, size_t t, const int32_t* idx, const uint8_t* player, int H,
-                          const uint32_t* shapes, uint8_t* valid, int8_t* land_y, uint8_t* cleared, uint32_t* after) {
+                          const uint32_t* shapes, uint8_t* valid, int8_t* land_y, uint8_t* cleared, uint32_t* after, size_t after_row) {
     const int i = (int)(t / 40), j = (int)(t % 40), r = j / 10, xi = j % 10;
     const size_t slot = idx ? (size_t)idx[i] : (size_t)i;
     const int p = player ? player[i] : 0;
@@ -373,14 +374,14 @@ TE_HD void enumerate_body(const uint32_t* state, int n_games, size_t t, const in
     bool ok = kind <= 6 && r < n_rot && q.x <= NCOL - 2 && fits_at(cx, q, shape, q.x, 0);
     int y = 0, gone = 0;
     if (ok) {
-        y = drop_distance(cx, q, shape);
+        y = drop_distance_bytes(cx, q, shape, shapes[32 + (((kind & 7) << 2) | rot)]);
         q.y = y;
         stamp(cx, q, shape);
     }
     valid[t] = ok ? 1 : 0;
     land_y[t] = (int8_t)y;
     if (after)
-        for (int c = 0; c < NCOL; c++) after[t * NCOL + c] = q.col[c];
+        for (int c = 0; c < NCOL; c++) after[after_row * NCOL + c] = q.col[c];
     if (ok) gone = clear_rows(cx, q);
     cleared[t] = (uint8_t)gone;
 }

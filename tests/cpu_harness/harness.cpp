@@ -332,8 +332,8 @@ int tetris_enumerate_drops(tetris_batch* b, const int32_t* idx, int n, const uin
                            uint8_t* cleared, uint32_t* after) {
     int rc = check_idx(b, idx, n); if (rc) return rc;
     for (size_t t = 0; t < (size_t)n * 40; t++) {
-        if (b->P == 1) enumerate_body<1>(b->state.data(), b->N, t, idx, player, b->H, SHAPES.s, valid, land_y, cleared, after);
-        else enumerate_body<2>(b->state.data(), b->N, t, idx, player, b->H, SHAPES.s, valid, land_y, cleared, after);
+        if (b->P == 1) enumerate_body<1>(b->state.data(), b->N, t, idx, player, b->H, SHAPES.s, valid, land_y, cleared, after, t);
+        else enumerate_body<2>(b->state.data(), b->N, t, idx, player, b->H, SHAPES.s, valid, land_y, cleared, after, t);
     }
     return TETRIS_OK;
 }
