@@ -202,6 +202,25 @@ def test_rng_tables_extend_past_two_chunks(kind):
 
 
 @pytest.mark.parametrize("kind", engines.ENGINE_PARAMS)
+@pytest.mark.parametrize("P,H,pieces", [(1, 20, (4,)), (1, 12, (2, 3)), (2, 20, (0, 1)), (2, 16, (5, 6, 4)), (1, 31, (0, 1, 2, 3, 4, 5, 6)),
+                                        (1, 4, (6,))])
+def test_rollout_piece_sets_and_heights(kind, P, H, pieces):
+    """Built-in rollouts for restricted piece sets (tetris_env.set_pieces: the piece map is cycled over the 7 slots, only
+    S/Z keeps the redraw loop open, gamePlay.cpp:218-230) and unusual heights, fused and unfused, against the oracle."""
+    n = 1024 if kind == "hip" else 128
+    seeds = orc.episode_seed(np.arange(n), 0)
+    eng = engines.make(kind, n, P, H, pieces, seeds=seeds)
+    eng2 = engines.make(kind, n, P, H, pieces, seeds=seeds)
+    ref = engines.make("oracle", n, P, H, pieces, seeds=seeds)
+    c1, _ = eng.rollout_random(4, 30)
+    c2, _ = eng2.rollout_random(120, 1)
+    _, c3 = ref.rollout_random(120)
+    assert c1.tolist() == c2.tolist() == c3.tolist()
+    engines.assert_same_state(eng, ref, where="fused")
+    engines.assert_same_state(eng2, ref, where="unfused")
+
+
+@pytest.mark.parametrize("kind", engines.ENGINE_PARAMS)
 @pytest.mark.parametrize("P", [1, 2])
 def test_rollout_random_matches_oracle(kind, P):
     """The built-in synthetic rollout (SURVEY §8d policy + auto-reset) against the oracle's: counters and
