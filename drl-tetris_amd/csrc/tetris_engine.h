@@ -75,7 +75,8 @@ __device__ __forceinline__ void te_stamp(int k, bool realtime = false) {
 // Test-only path counters (tests/cpu_harness defines TE_PATH_COUNTERS): how often the rare branches of the key interpreter
 // ran, so the parity tests can assert that they reached them.  Nothing in device or product builds.
 #if defined(TE_PATH_COUNTERS) && !defined(__HIPCC__)
-enum PathCounter { PC_KICK = 0, PC_KICK_2ND, PC_KICK_3RD, PC_KICK_FAILED, PC_KICK_DOWN, PC_DROP_EXACT, PC_RT_OFF_SPAWN, PC_NCOUNTERS };
+enum PathCounter { PC_KICK = 0, PC_KICK_2ND, PC_KICK_3RD, PC_KICK_FAILED, PC_KICK_DOWN, PC_DROP_EXACT, PC_RT_OFF_SPAWN,
+                   PC_GARBAGE_ROW, PC_GARBAGE_LIFT2, PC_DEATH_GARBAGE, PC_DEATH_SPAWN, PC_TIMER_LOCK, PC_KEY_KICK, PC_KEY_KICK_FAILED, PC_NCOUNTERS };
 extern unsigned long long te_path_count[PC_NCOUNTERS];
 #define TE_COUNT(i) (te_path_count[i]++)
 #else
@@ -602,7 +603,7 @@ TE_HD bool spawn_next(const Ctx& cx, Player& q, uint32_t seed16, uint32_t& statu
         q.pf_ok = 0;
     }
     uint32_t shape = shape_of(cx, q.kind, q.rot);
-    if (!fits_at(cx, q, shape, q.x, 0)) { stamp(cx, q, shape); return true; }
+    if (!fits_at(cx, q, shape, q.x, 0)) { stamp(cx, q, shape); TE_COUNT(PC_DEATH_SPAWN); return true; }
     return false;
 }
 
@@ -671,10 +672,11 @@ TE_HD bool push_garbage(const Ctx& cx, Player& q, uint32_t seed16, uint32_t& sta
     if (cx.tint)
         for (int k = 0; k < 3; k++)
             for (int c = 0; c < NCOL; c++) q.tint[k][c] = (q.tint[k][c] >> 1) | (c == hole ? 0u : bottom);
+    TE_COUNT(PC_GARBAGE_ROW);
     if (q.y > 0) q.y--;
     if (!fits_at(cx, q, shape_of(cx, q.kind, q.rot), q.x, q.y)) {
-        if (q.y > 0) q.y--;
-        else return true;
+        if (q.y > 0) { q.y--; TE_COUNT(PC_GARBAGE_LIFT2); }
+        else { TE_COUNT(PC_DEATH_GARBAGE); return true; }
     }
     return false;
 }
@@ -687,6 +689,7 @@ TE_HD int tick(const Ctx& cx, Player& q, int ms, uint32_t seed16, uint32_t& stat
 #endif
     if (gravity_due(q, q.time_ms)) soft_drop(cx, q);
     if (q.lock_armed && q.time_ms > q.lock_time && !soft_drop(cx, q)) {    // DropDelay.cpp:43-48
+        TE_COUNT(PC_TIMER_LOCK);
         lock_piece(cx, q);                                                  // gamePlay.cpp:38-46 hd
         return settle(cx, q, seed16, status);
     }
@@ -788,7 +791,8 @@ TE_HD bool rotate_shape_band(const Ctx& cx, Player& q, int nr, uint32_t shape, u
     else if (fits_band(b1, shape, q.x + 1)) { dx = 1; dy = 1; }
     else if (fits_band(b0, shape, q.x - 2)) { dx = -2; }
     else if (fits_band(b0, shape, q.x + 2)) { dx = 2; }
-    if (dx == 99) return false;
+    if (dx == 99) { TE_COUNT(PC_KEY_KICK_FAILED); return false; }
+    TE_COUNT(PC_KEY_KICK);
     q.rot = nr; q.x += dx; q.y += dy;
     if (dy) { b0 = b1; b1_ok = false; }
     return true;

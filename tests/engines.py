@@ -46,7 +46,8 @@ def assert_same_state(eng, ref, idx=None, where=""):
     assert np.array_equal(lw_a, lw_b), f"{where}: last_winner"
 
 
-PATH_COUNTERS = ["kick", "kick_2nd", "kick_3rd", "kick_failed", "kick_down", "drop_exact", "rt_off_spawn"]
+PATH_COUNTERS = ["kick", "kick_2nd", "kick_3rd", "kick_failed", "kick_down", "drop_exact", "rt_off_spawn",
+                 "garbage_row", "garbage_lift2", "death_garbage", "death_spawn", "timer_lock", "key_kick", "key_kick_failed"]
 
 
 def harness_path_counts():

@@ -24,8 +24,9 @@ from tests.golden.ref_driver import RefGame  # noqa: E402
 MAXK = 32
 
 
-def record_trace(name, P, H, pieces, seed0, steps, policy, sloppiness=0.0, early_reset_every=0, record_actions=False):
-    """One game driven for `steps` env-steps; reset with seed0 + 17*episode on done."""
+def record_trace(name, P, H, pieces, seed0, steps, policy, sloppiness=0.0, early_reset_every=0, record_actions=False, solo=None):
+    """One game driven for `steps` env-steps; reset with seed0 + 17*episode on done.
+    solo = p: only player p ever acts (the others get [0] every step, tetris_environment.py:102-107)."""
     rng = np.random.default_rng(abs(hash((name, seed0))) % (2**32))
     ref = RefGame(P, H, 10, pieces=pieces, seed=seed0)
     shadow = orc.OracleBatch(1, P, H, 10, pieces=pieces, seeds=seed0)   # only feeds the greedy policy
@@ -64,7 +65,7 @@ def record_trace(name, P, H, pieces, seed0, steps, policy, sloppiness=0.0, early
     do_reset(seed0)     # tetris_environment.__init__ always resets once (tetris_environment.py:40-41)
     episode = 0
     for s in range(steps):
-        player = s % P
+        player = s % P if solo is None else solo
         lists = snap_actions(player)
         if policy == "actions":
             keys = lists[int(rng.integers(len(lists)))]
@@ -153,31 +154,49 @@ def rng_kat():
     return out
 
 
+TRACES = {
+    "rt_1p": dict(P=1, H=20, pieces="all", seed0=1000, steps=1500, policy="rt"),
+    "rt_2p": dict(P=2, H=20, pieces="all", seed0=1000, steps=2500, policy="rt", early_reset_every=333),
+    "rt_2p_neg": dict(P=2, H=20, pieces="all", seed0=-5, steps=1200, policy="rt"),
+    "keys_1p": dict(P=1, H=20, pieces="all", seed0=40000, steps=1500, policy="keys"),
+    "keys_2p": dict(P=2, H=20, pieces="all", seed0=7, steps=2500, policy="keys"),
+    "keys_2p_22": dict(P=2, H=22, pieces="all", seed0=31000, steps=1500, policy="keys"),
+    "greedy_1p": dict(P=1, H=20, pieces="all", seed0=1000, steps=3000, policy="greedy"),
+    "greedy_2p": dict(P=2, H=20, pieces="all", seed0=1000, steps=3000, policy="greedy", sloppiness=0.05),
+    "greedy_2p_b": dict(P=2, H=22, pieces="all", seed0=77, steps=2500, policy="greedy", sloppiness=0.15),
+    "greedy_1p_io": dict(P=1, H=20, pieces=[4, 6], seed0=9, steps=1500, policy="greedy", sloppiness=0.02),
+    "greedy_2p_o": dict(P=2, H=20, pieces=[6], seed0=11, steps=1500, policy="greedy", sloppiness=0.02),
+    "rt_2p_sz": dict(P=2, H=20, pieces=[2, 3], seed0=5, steps=800, policy="rt"),
+    "drop_2p": dict(P=2, H=20, pieces="all", seed0=1000, steps=120, policy="drop"),
+    # get_actions() lists (TestField.cpp:64-415) recorded before every step; the policy plays one of them, so
+    # tucks and spins create overhangs that later enumerations have to reach
+    "actions_2p": dict(P=2, H=20, pieces="all", seed0=4, steps=500, policy="actions", record_actions=True),
+    "actions_1p_22": dict(P=1, H=22, pieces="all", seed0=21, steps=400, policy="actions", record_actions=True),
+    "actions_2p_greedy": dict(P=2, H=20, pieces="all", seed0=3, steps=300, policy="greedy", sloppiness=0.3, record_actions=True),
+    # player 0 clears and sends, player 1 never acts: its board fills with garbage rows only, until a pushed row cannot
+    # lift the freshly dealt piece any more (gamePlay.cpp:179-192 pushGarbage -> death) or the spawn collides
+    "garbage_flood_2p": dict(P=2, H=20, pieces=[6, 4], seed0=23, steps=2500, policy="greedy", sloppiness=0.02, solo=0),
+    "garbage_flood_2p_12": dict(P=2, H=12, pieces=[6], seed0=8, steps=1500, policy="greedy", sloppiness=0.0, solo=0),
+}
+
+
 def main():
+    """no arguments: every trace + the tables (NOTE: the random policies are seeded from hash((name, seed)), which
+    differs between Python processes unless PYTHONHASHSEED is fixed — regenerate single traces by name instead:
+        python tests/golden/make_golden.py garbage_flood_2p ...)"""
     orc.build()
     if not orc.ref_available():
         sys.exit("oracle/_ref is not built and /root/reference is absent: cannot generate fixtures here")
     allp = [0, 1, 2, 3, 4, 5, 6]
-    record_trace("rt_1p", 1, 20, allp, 1000, 1500, "rt")
-    record_trace("rt_2p", 2, 20, allp, 1000, 2500, "rt", early_reset_every=333)
-    record_trace("rt_2p_neg", 2, 20, allp, -5, 1200, "rt")
-    record_trace("keys_1p", 1, 20, allp, 40000, 1500, "keys")
-    record_trace("keys_2p", 2, 20, allp, 7, 2500, "keys")
-    record_trace("keys_2p_22", 2, 22, allp, 31000, 1500, "keys")
-    record_trace("greedy_1p", 1, 20, allp, 1000, 3000, "greedy")
-    record_trace("greedy_2p", 2, 20, allp, 1000, 3000, "greedy", sloppiness=0.05)
-    record_trace("greedy_2p_b", 2, 22, allp, 77, 2500, "greedy", sloppiness=0.15)
-    record_trace("greedy_1p_io", 1, 20, [4, 6], 9, 1500, "greedy", sloppiness=0.02)
-    record_trace("greedy_2p_o", 2, 20, [6], 11, 1500, "greedy", sloppiness=0.02)
-    record_trace("rt_2p_sz", 2, 20, [2, 3], 5, 800, "rt")
-    record_trace("drop_2p", 2, 20, allp, 1000, 120, "drop")
-    # get_actions() lists (TestField.cpp:64-415) recorded before every step; the policy plays one of them, so
-    # tucks and spins create overhangs that later enumerations have to reach
-    record_trace("actions_2p", 2, 20, allp, 4, 500, "actions", record_actions=True)
-    record_trace("actions_1p_22", 1, 22, allp, 21, 400, "actions", record_actions=True)
-    record_trace("actions_2p_greedy", 2, 20, allp, 3, 300, "greedy", sloppiness=0.3, record_actions=True)
-    np.savez_compressed(os.path.join(HERE, "rotation_table.npz"), table=rotation_table())
-    np.savez_compressed(os.path.join(HERE, "rng_kat.npz"), **rng_kat())
+    names = sys.argv[1:] or list(TRACES)
+    for name in names:
+        kw = dict(TRACES[name])
+        if kw["pieces"] == "all":
+            kw["pieces"] = allp
+        record_trace(name, kw.pop("P"), kw.pop("H"), kw.pop("pieces"), kw.pop("seed0"), kw.pop("steps"), kw.pop("policy"), **kw)
+    if not sys.argv[1:]:
+        np.savez_compressed(os.path.join(HERE, "rotation_table.npz"), table=rotation_table())
+        np.savez_compressed(os.path.join(HERE, "rng_kat.npz"), **rng_kat())
     print("done")
 
 
