@@ -177,7 +177,8 @@ def main():
     # rank r owns global games [r*N, (r+1)*N): distinct policy stream and seed schedule per rank, no collective
     # on the data path; ShardedRollout brackets the timed launches with barrier + synchronize on both sides and
     # reduces time (MAX) and counters (SUM) over the ranks.
-    shard = sharded.ShardedRollout(N, P, args.height, 10, rank=rank, world=world, device=local_rank, dist=dist)
+    shard = sharded.ShardedRollout(N, P, args.height, 10, rank=rank, world=world, device=local_rank, dist=dist,
+                                   lib_path=os.environ.get("BENCH_LIB_PATH"))   # (set only to rehearse the N>1 launch without GPUs)
     if args.warmup > 0:
         shard.run(args.warmup, S)                     # untimed warm-up
     res = shard.run(args.steps, S)                    # exactly K timed launches
@@ -187,7 +188,7 @@ def main():
     if rank == 0:
         env_steps = int(counters[0])
         assert env_steps == world * N * S * args.steps, (env_steps, world, N, S, args.steps)
-        launch_us = ev_ms * 1e3 / args.steps                      # HIP events on the launch stream
+        launch_us = (ev_ms if ev_ms > 0 else wall * 1e3) * 1e3 / args.steps   # HIP events on the launch stream (the CPU rehearsal library has none: wall clock)
         algo_bytes = ALGO_BYTES[P] * N * S                        # per launch, per GPU
         achieved = algo_bytes / (launch_us * 1e-6) / 1e9
         traffic = None
