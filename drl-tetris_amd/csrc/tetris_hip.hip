@@ -222,8 +222,8 @@ __global__ __launch_bounds__(256) void k_observe_packed_bytes(const uint32_t* st
     const int nb = (n - first < 256) ? n - first : 256;
     for (int sl = 0; sl < P; sl++) {
         if (i < n) {
-            const size_t slot = idx ? (size_t)idx[i] : (size_t)i;
-            const int me = player ? player[i] : 0;
+            const size_t slot = safe_slot(idx, i, n_games);
+            const int me = safe_player(player, i, P);
             const int p = (sl == 0) ? me : (P - 1 - me);
             uint8_t vec[12];
             const int kind = observe_board(state, n_games, slot, P, p, H, s_cells + (size_t)threadIdx.x * cells, vec);
@@ -260,8 +260,8 @@ __global__ __launch_bounds__(BLOCK) void k_observe_packed(const uint32_t* state,
     const int nb = (n - first < BLOCK) ? n - first : BLOCK;
     for (int sl = 0; sl < P; sl++) {
         if (i < n) {
-            const size_t slot = idx ? (size_t)idx[i] : (size_t)i;
-            const int me = player ? player[i] : 0;
+            const size_t slot = safe_slot(idx, i, n_games);
+            const int me = safe_player(player, i, P);
             const int p = (sl == 0) ? me : (P - 1 - me);
             const size_t ws = (size_t)P * n_games;
             const uint32_t* s = state + (size_t)p * n_games + slot;

@@ -47,6 +47,18 @@ enum Mode { M_INIT, M_RESET, M_MAKE, M_FINISH, M_STEP_KEYS, M_STEP_RT, M_ROLLOUT
 
 struct LaneCounters { unsigned long long steps, episodes, lines, sent; };   // used by the CPU test harness only
 
+// Device-resident index arrays (the *_dev entry points) cannot be validated on the host: an out-of-range entry is clamped
+// into the batch instead of becoming an out-of-bounds access (host arrays are rejected with TETRIS_E_ARG before launch).
+TE_HD size_t safe_slot(const int32_t* idx, int i, int n_games) {
+    if (!idx) return (size_t)i;
+    const uint32_t v = (uint32_t)idx[i];
+    return (size_t)(v < (uint32_t)n_games ? v : (uint32_t)n_games - 1u);
+}
+TE_HD int safe_player(const uint8_t* player, int i, int P) {
+    const int v = player ? (int)player[i] : 0;
+    return v < P ? v : P - 1;
+}
+
 TE_HD Ctx make_ctx(const KArgs& a, const uint32_t* shapes, bool tint = false, bool queue = true) {
     Ctx cx;
     cx.shapes = shapes;
@@ -357,8 +369,8 @@ template <int P>
 TE_HD void enumerate_body(const uint32_t* state, int n_games, size_t t, const int32_t* idx, const uint8_t* player, int H,
                           const uint32_t* shapes, uint8_t* valid, int8_t* land_y, uint8_t* cleared, uint32_t* after, size_t after_row) {
     const int i = (int)(t / 40), j = (int)(t % 40), r = j / 10, xi = j % 10;
-    const size_t slot = idx ? (size_t)idx[i] : (size_t)i;
-    const int p = player ? player[i] : 0;
+    const size_t slot = safe_slot(idx, i, n_games);
+    const int p = safe_player(player, i, P);
     const size_t ws = (size_t)P * n_games;
     const uint32_t* s = state + (size_t)p * n_games + slot;
     Player q;
@@ -393,8 +405,8 @@ TE_HD void actions_body(const uint32_t* state, int n_games, size_t t, const int3
                         const uint32_t* shapes, uint8_t* count, uint8_t* lens, uint8_t* keys, int max_lists, int max_keys,
                         uint32_t* status) {
     const int i = (int)(t / 40), j = (int)(t % 40), r = j / 10, xi = j % 10;
-    const size_t slot = idx ? (size_t)idx[i] : (size_t)i;
-    const int p = player ? player[i] : 0;
+    const size_t slot = safe_slot(idx, i, n_games);
+    const int p = safe_player(player, i, P);
     const size_t ws = (size_t)P * n_games;
     const uint32_t* s = state + (size_t)p * n_games + slot;
     Probe pr;

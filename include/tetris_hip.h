@@ -18,6 +18,8 @@
  *  - a batch is not thread-safe; different batches are independent (one HIP stream each).
  *  - functions ending in _dev take DEVICE pointers, enqueue on the batch's stream and return
  *    without synchronising (zero-copy callers, benchmarks); all others are synchronous.
+ *    Host index / player arrays are validated (TETRIS_E_ARG); device-resident ones cannot be, so an
+ *    out-of-range game index or player in a d_idx / d_player array is clamped into the batch by the kernel.
  *  - board height 4..31, width 10 (the reference hard-codes 10, gamePlay.cpp:202), 1 or 2 players.
  */
 #ifndef TETRIS_HIP_H

@@ -46,3 +46,37 @@ def test_zero_copy_loop_matches_oracle():
     assert np.array_equal(visual[1].cpu().numpy(), (rec["field"][:, 1, :H] > 0).astype(np.uint8))
     assert np.array_equal(piece[0].cpu().numpy(), rec["piece"][:, 0])
     batch.close()
+
+
+def test_out_of_range_device_indices_are_clamped():
+    """d_idx / d_player live in HBM and cannot be validated by the host: the kernels clamp them into the batch
+    (include/tetris_hip.h), so a bad entry reads the last game / last player instead of faulting."""
+    import ctypes as C
+
+    import torch
+    pkg = ge.package()
+    n, P, H = 512, 2, 20
+    batch = pkg.TetrisBatch(n, P, H, 10, seeds=orc.episode_seed(np.arange(n), 0), device=0)
+    batch.rollout_random(10, 1)
+    ptr = lambda t: C.c_void_p(t.data_ptr())
+    m = 64
+    bad = torch.tensor([5, -1, 10**6, n, n - 1, 2**31 - 1] + [7] * (m - 6), dtype=torch.int32, device="cuda")
+    good = bad.clone().clamp_(0, n - 1)
+    good[1] = n - 1                                    # negative reads as a huge unsigned value
+    pl_bad = torch.tensor([0, 1, 7, 255] * (m // 4), dtype=torch.uint8, device="cuda")
+    pl_good = pl_bad.clamp(max=P - 1)
+    outs = []
+    for idx, pl in ((bad, pl_bad), (good, pl_good)):
+        visual = torch.zeros(P * m * H * 10, dtype=torch.uint8, device="cuda")
+        vector = torch.zeros(P * m * 12, dtype=torch.uint8, device="cuda")
+        piece = torch.zeros(P * m, dtype=torch.uint8, device="cuda")
+        batch._check(batch.lib.tetris_observe_packed_dev(batch._h, ptr(idx), m, ptr(pl), ptr(visual), ptr(vector), ptr(piece)))
+        valid = torch.zeros(m * 40, dtype=torch.uint8, device="cuda")
+        land = torch.zeros(m * 40, dtype=torch.int8, device="cuda")
+        cleared = torch.zeros(m * 40, dtype=torch.uint8, device="cuda")
+        batch._check(batch.lib.tetris_enumerate_drops_dev(batch._h, ptr(idx), m, ptr(pl), ptr(valid), ptr(land), ptr(cleared), None))
+        batch.sync()
+        outs.append([t.cpu().numpy() for t in (visual, vector, piece, valid, land, cleared)])
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
+    batch.close()
