@@ -257,6 +257,34 @@ class tetris_environment_vector:
         p = self.settings["pieces"]
         return [(p * 7)[:7] for _ in self._idx(env)]
 
+    # ------------------------------------------------------------------ pickling (tetris_environment_vector.py:179-191)
+    def __getstate__(self):
+        """Everything but the device handle: settings, reward bookkeeping and the games as snapshot words.  Unlike the
+        reference's pickle (PythonHandle.h:180-182 drops the generators) the RNG positions survive.  A `seed_source` that
+        cannot be pickled (a lambda) is replaced by the default wall-clock source on load."""
+        d = {k: v for k, v in self.__dict__.items() if k not in ("backend", "state_processor", "_seed_source")}
+        d["settings"] = dict(self.settings)
+        try:
+            import pickle
+            pickle.dumps(self.settings["seed_source"])
+        except Exception:
+            d["settings"]["seed_source"] = None
+        if type(d["settings"]["state_processor"]) is not str:
+            raise TypeError("a vector env with a custom state_processor callable cannot be pickled; name it in state_processors.func_dict")
+        d["_games"] = self.backend.snapshot()
+        return d
+
+    def __setstate__(self, d):
+        games = d.pop("_games")
+        # the constructor draws seeds (batch creation + the initial reset): build with a throw-away source so that the
+        # unpickled seed source continues exactly where the pickled one stood
+        fresh = tetris_environment_vector(d["n_envs"], d["env_type"], settings=dict(d["settings"], seed_source=lambda: 0),
+                                          _lib_path=d["_lib_path"])
+        self.__dict__.update(fresh.__dict__)
+        self.__dict__.update(d)
+        self._seed_source = self.settings["seed_source"] or (lambda: int(time.time()))
+        self.backend.restore(games)
+
     def __str__(self, env=None):
         width = max(len(k) for k in self.settings)
         body = "".join("\t{:{}}\t{}\n".format(k, width, v) for k, v in self.settings.items())

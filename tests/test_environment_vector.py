@@ -220,3 +220,38 @@ def test_single_env_sandbox_api(kind):
     twin.perform_action(edt.action([7]), player=0)
     assert not np.array_equal(twin.backend.snapshot(), env.backend.snapshot())
     assert env.get_winner() is None and "game_size" in str(env)
+
+
+@pytest.mark.parametrize("kind", engines.ENGINE_PARAMS)
+def test_pickle_round_trip_of_env_and_states(kind):
+    """tetris_environment_vector.__getstate__/__setstate__ (tetris_environment_vector.py:179-191) and `state` objects
+    (workers ship them to the trainer): a pickled env continues exactly like the original, RNG positions included
+    (_Clock is a picklable seed source, so later resets agree as well)."""
+    import pickle
+    settings = {"game_size": [20, 10], "n_players": 2, "pieces": [0, 1, 2, 3, 4, 5, 6], "seed_source": _Clock(50)}
+    _, env_mod, env = _make_env(kind, 6, settings)
+    rng = np.random.default_rng(3)
+    for s in range(12):
+        acts = env.get_actions(player=s % 2)
+        env.perform_action([a[int(rng.integers(len(a)))] for a in acts], player=s % 2)
+    states = env.get_state()
+    twin = pickle.loads(pickle.dumps(env))
+    again = [pickle.loads(pickle.dumps(st)) for st in states]
+    assert all(np.array_equal(a.backend_state.blob, b.backend_state.blob) for a, b in zip(again, states))
+    assert np.array_equal(twin.backend.snapshot(), env.backend.snapshot())
+    for s in range(60):
+        p = s % 2
+        a1, a2 = env.get_actions(player=p), twin.get_actions(player=p)
+        assert [list(map(list, x)) for x in a1] == [list(map(list, x)) for x in a2]
+        pick = [int(rng.integers(len(a))) for a in a1]
+        r1, d1 = env.perform_action([a[k] for a, k in zip(a1, pick)], player=p)
+        r2, d2 = twin.perform_action([a[k] for a, k in zip(a2, pick)], player=p)
+        assert list(d1) == list(d2) and [float(x()) for x in r1] == [float(x()) for x in r2]
+        dead = [i for i, d in enumerate(d1) if d]
+        env.reset(env=dead)
+        twin.reset(env=dead)
+    assert np.array_equal(twin.backend.snapshot(), env.backend.snapshot())
+    # a restored state sets an env like the original state does
+    env.set(again[0], env=[0])
+    twin.set(states[0], env=[0])
+    assert np.array_equal(twin.backend.snapshot(np.array([0], np.int32)), env.backend.snapshot(np.array([0], np.int32)))
