@@ -26,6 +26,22 @@ def test_64k_boards_rollout_bit_exact(P, steps):
         engines.assert_same_state(eng, ref, idx=idx, where=f"games {lo}..")
 
 
+@pytest.mark.parametrize("P,steps,fused", [(1, 3000, 30), (2, 2000, 20)])
+def test_64k_boards_long_fused_rollout_bit_exact(P, steps, fused):
+    """A soak at full size: 2-3 thousand env-steps per board (1.3-2.0e8 env-steps, ~1e7 episodes), `fused` steps per launch,
+    against the oracle on all host cores — counters and every board's complete final state."""
+    n = 65536
+    seeds = orc.episode_seed(np.arange(n), 0)
+    eng = engines.make("hip", n, P, seeds=seeds)
+    ref = engines.make("oracle", n, P, seeds=seeds)
+    c_gpu, _ = eng.rollout_random(steps // fused, fused)
+    _, c_ref = ref.rollout_random(steps, threads=min(32, len(os.sched_getaffinity(0))))
+    assert c_gpu.tolist() == c_ref.tolist() and int(c_gpu[0]) == n * steps
+    for lo in range(0, n, 8192):
+        idx = np.arange(lo, lo + 8192, dtype=np.int32)
+        engines.assert_same_state(eng, ref, idx=idx, where=f"games {lo}..")
+
+
 def test_batch_independence_and_order_invariance():
     """Games never interact: stepping a permuted / split batch gives the same per-game results
     (the property that makes sharding across GPUs collective-free)."""
