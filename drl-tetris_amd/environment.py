@@ -14,6 +14,7 @@ undefined names: tetris_environment_vector.py:65,91,95,112,160) the
 implemented.  Seeds: the reference seeds from time(NULL) (PythonHandle.cpp:68-71); here
 `settings["seed_source"]` (a callable -> int, default wall clock seconds) is asked once per reset call.
 """
+import itertools
 import time
 
 import numpy as np
@@ -80,6 +81,7 @@ class tetris_environment_vector:
         self.backend = TetrisBatch(n_envs, self.n_players, self.height, self.width, pieces=s["pieces"], seeds=seed,
                                    device=s["device"], lib_path=_lib_path, colours=s["field_colours"])
         self._env_ids = list(range(n_envs))
+        self._shared_zero = self._zero_reward()
         self.done = np.zeros(n_envs, bool)
         self.rounds_played = np.zeros(n_envs, np.int64)
         self.round_reward = [[self._zero_reward() for _ in self.player_idxs] for _ in range(n_envs)]
@@ -112,13 +114,17 @@ class tetris_environment_vector:
         return base
 
     def _pack(self, actions, players, n):
-        K = max(1, max(len(a) for a in actions))
-        keys = np.zeros((n, self.n_players, K), np.uint8)
-        lens = np.ones((n, self.n_players), np.uint8)          # the other players get the null action [0]
-        for i, (a, p) in enumerate(zip(actions, players)):
+        for a in actions:
             assert type(a) is action, f"perform_action(action a, int p) was called with type(action)={type(a)}"
-            keys[i, p, : len(a)] = a
-            lens[i, p] = len(a)
+        length = np.fromiter(map(len, actions), np.int64, n)
+        total = int(length.sum())
+        keys = np.zeros((n, self.n_players, max(1, int(length.max(initial=0)))), np.uint8)
+        lens = np.ones((n, self.n_players), np.uint8)          # the other players get the null action [0]
+        who = np.asarray(players, np.int64)
+        rows = np.repeat(np.arange(n), length)
+        cols = np.arange(total) - np.repeat(np.cumsum(length) - length, length)
+        keys[rows, who[rows], cols] = np.fromiter(itertools.chain.from_iterable(actions), np.uint8, total)
+        lens[np.arange(n), who] = length
         return keys, lens
 
     # ------------------------------------------------------------------ env interface
@@ -141,15 +147,25 @@ class tetris_environment_vector:
         assert len(actions) == n and len(players) == n
         keys, lens = self._pack(actions, players, n)
         done, _lines, dead = self.backend.step_keys(keys, lens, ms=self.settings["time_elapsed_each_action"], idx=idx)
-        rewards, dones = [None] * n, [None] * n
-        for j, (i, p) in enumerate(zip(idx, players)):
-            self.done[i] = bool(done[j])
-            r = maingoal_reward([self._reward(done[j], dead[j], p)])
-            self.last_reward[i][p] = r
-            self.round_reward[i][p] = self.round_reward[i][p] + r
-            self.tot_reward[i][p] = self.tot_reward[i][p] + r
-            rewards[j], dones[j] = r, bool(done[j])
-        return rewards, dones
+        # reward_fcn (tetris_environment.py:135-149) is 0 unless the round just ended: only those envs get a reward object of
+        # their own and an update of the running sums (x + 0 leaves the sums as they are); the others share one zero reward
+        # (reward objects are never modified in place: `+` / `-` return new ones).  At 8k envs this is 20x less Python time.
+        done_b = done.astype(bool)
+        self.done[idx] = done_b
+        zero = self._shared_zero
+        rewards = [zero] * n
+        for j in np.nonzero(done_b)[0]:
+            i, p = idx[j], players[j]
+            base = self._reward(True, dead[j], p)
+            if base != 0:
+                r = maingoal_reward([base])
+                rewards[j] = r
+                self.round_reward[i][p] = self.round_reward[i][p] + r
+                self.tot_reward[i][p] = self.tot_reward[i][p] + r
+        last = self.last_reward
+        for j in range(n):
+            last[idx[j]][players[j]] = rewards[j]
+        return rewards, done_b.tolist()
 
     def get_state(self, env=None):
         idx = self._idx(env)
