@@ -97,4 +97,34 @@ bytes_per_call = 2 * n * (44 + 213)
 out["observe_packed_64k_2p_device"] = {"us_per_call": us, "player_boards_per_s": 2 * n / (us * 1e-6), "algorithmic_bytes": bytes_per_call,
                                        "GBps": bytes_per_call / (us * 1e-6) / 1e9, "frac_of_8TBps": bytes_per_call / (us * 1e-6) / 8e12}
 b.close()
+
+# the NN-policy shape: actions arrive as device arrays, outputs stay on the device (tetris_step_rt_dev), no resets inside the
+# timed region (boards that end stay round_over, as between perform_action and reset in the reference's loop)
+for P in (1, 2):
+    b = pkg.TetrisBatch(65536, P, 20, 10, seeds=np.arange(65536))
+    n = 65536
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    K = 32
+    rots = torch.randint(0, 4, (K, n), generator=gen, device="cuda", dtype=torch.uint8)
+    trans = torch.randint(0, 10, (K, n), generator=gen, device="cuda", dtype=torch.uint8)
+    who = torch.randint(0, P, (K, n), generator=gen, device="cuda", dtype=torch.uint8)
+    done, lines, dead = torch.zeros(n, **dv), torch.zeros(P * n, **dv), torch.zeros(P * n, **dv)
+    torch.cuda.synchronize()
+    # windows of 4 and of 12 launches on freshly reset boards; the slope (t12 - t4) / 8 is the cost of one launch without the
+    # event pair and the pipeline fill of a short window (steps 4..11 of an episode: hardly any game has ended yet)
+    t = {4: 0.0, 12: 0.0}
+    reps = 40
+    for rep in range(reps):
+        for w in (4, 12):
+            b.reset(None, seeds=((12345 + 7919 * np.arange(n) + 104729 * rep) & 0xFFFF).astype(np.uint16).view(np.int16))
+            b.timer_start()
+            for k in range(w):
+                j = (rep * 12 + k) % K
+                b._check(b.lib.tetris_step_rt_dev(b._h, ptr(rots[j]), ptr(trans[j]), ptr(who[j]), 400, ptr(done), ptr(lines), ptr(dead)))
+            t[w] += b.timer_stop() * 1e3
+    us = (t[12] - t[4]) / reps / 8
+    algo = (389 if P == 1 else 774) * n
+    out[f"step_rt_dev_{P}p_64k_device"] = {"us_per_call": us, "env_steps_per_s": n / (us * 1e-6), "algorithmic_bytes": algo,
+                                            "GBps": algo / (us * 1e-6) / 1e9, "frac_of_8TBps": algo / (us * 1e-6) / 8e12}
+    b.close()
 print(json.dumps(out))
