@@ -91,6 +91,7 @@ __global__ __launch_bounds__(256) void k_duo(KArgs a) {
         load_game_words<1>(a.gstate, N, (size_t)gi, g);
         load_player(a.state, (uint32_t)(side * a.n_games + gi) * 4u, 2 * N, q, false);
         if (MODE == M_ROLLOUT) policy_draw(a, (uint32_t)gi, a.first_step, g.draw0, g.draw1);   // under the loads (see game_load)
+        else { g.draw0 = a.rot[gi]; g.draw1 = (uint32_t)a.trans[gi] | ((a.player ? (uint32_t)a.player[gi] : 0u) << 8); }
     }
     s_shapes[lane] = shape_word;
     __builtin_amdgcn_wave_barrier();
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(256) void k_duo(KArgs a) {
                 r = (int)(g.draw0 & 3u); t = (int)(g.draw1 % 10u); acting = (int)(step % 2ull);
                 prefetch_reset(cx, episode_seed(a.game_offset + (uint32_t)gi, g.episode + 1), rpf);
             } else {
-                r = a.rot[gi] & 3; t = a.trans[gi]; acting = a.player ? a.player[gi] : 0;
+                r = (int)(g.draw0 & 3u); t = (int)(g.draw1 & 0xFFu); acting = (int)(g.draw1 >> 8);
             }
             prefetch_next(cx, q, g.seed16, g.status);
             sent_start = q.lines_sent;

@@ -125,6 +125,8 @@ TE_HD void game_load(const KArgs& a, int i, Game<P>& g) {
     if (MODE != M_INIT && MODE != M_SPLIT_INIT) load_game<P>(a.state, a.gstate, (size_t)a.n_games, slot, g, TINT, P > 1 || MODE == M_SPLIT_RESET);   // split batches: 1-player layout WITH a queue
     // the first step's draw depends on kernel arguments only: its 40 dependent multiplies run while the state loads are in flight
     if (MODE == M_ROLLOUT) policy_draw(a, (uint32_t)slot, a.first_step, g.draw0, g.draw1);
+    // (r, t) actions: the three action bytes are requested together with the state, not after it has arrived
+    if (MODE == M_STEP_RT) { g.draw0 = a.rot[i]; g.draw1 = (uint32_t)a.trans[i] | ((a.player ? (uint32_t)a.player[i] : 0u) << 8); }
 }
 
 // Phase 2: step and store.
@@ -157,7 +159,7 @@ TE_HD void game_run(const KArgs& a, int i, const uint32_t* shapes, Game<P>& g, L
     } else if (MODE == M_STEP_RT) {
         TE_UNROLL
         for (int p = 0; p < P; p++) prefetch_next(cx, g.pl[p], g.seed16, g.status);
-        make_rt<P>(cx, g, a.player ? a.player[i] : 0, a.rot[i] & 3, a.trans[i]);
+        make_rt<P>(cx, g, (int)(g.draw1 >> 8), (int)(g.draw0 & 3u), (int)(g.draw1 & 0xFFu));
         int done = finish_game<P>(cx, g, a.ms);
         write_outputs<P>(a, i, g, done);
     } else if (MODE == M_ROLLOUT) {
