@@ -111,7 +111,8 @@ def bench_split(args, mod, dist, rank, world, local_rank):
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     tot = torch.tensor([int(x) for x in so.batch.rollout_totals()], dtype=torch.int64, device=dev)
     if rank % 2:
-        tot[0] = 0                                   # episodes are counted once per game (by side 0)
+        tot[0] = 0                                   # env-steps and episodes are counted once per game (by side 0)
+        tot[1] = 0
     dist.all_reduce(tot, op=dist.ReduceOp.SUM)
     if rank == 0:
         wall = float(t[0])
@@ -129,7 +130,8 @@ def bench_split(args, mod, dist, rank, world, local_rank):
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "kernel": "k_split<0..2> + 3 all-gathers per step (wall time, not kernel time)",
                          "algorithmic_bytes_per_launch": algo, "launch_us": per_step_us},
-            "episodes": int(tot[0]), "lines_cleared": int(tot[1]), "garbage_sent": int(tot[2]), "cpu_baseline": None}))
+            "env_steps_counted_on_device": int(tot[0]), "episodes": int(tot[1]), "lines_cleared": int(tot[2]), "garbage_sent": int(tot[3]),
+            "cpu_baseline": None}))
     so.close()
     dist.destroy_process_group()
 

@@ -59,6 +59,8 @@ _SIGNATURES = {
     "tetris_step_keys": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "tetris_step_rt": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "tetris_step_rt_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "tetris_step_rt_dev_ex": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "tetris_reset_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "tetris_observe_records": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "tetris_snapshot": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "tetris_restore": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
@@ -76,6 +78,7 @@ _SIGNATURES = {
     "tetris_rollout_totals": (C.c_int, [C.c_void_p, C.c_void_p]),
     "tetris_set_stream": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "tetris_rollout_random": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_uint32, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p]),
+    "tetris_rollout_launch": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_uint32, C.c_uint64, C.c_int, C.c_void_p]),
     "tetris_device_state": (C.c_void_p, [C.c_void_p]),
     "tetris_stream": (C.c_void_p, [C.c_void_p]),
 }
@@ -306,9 +309,17 @@ class TetrisBatch:
     def split_rollout_stage(self, stage, step, words=None, out=None, policy_seed=0xD71, ms=400):
         self._check(self.lib.tetris_split_rollout_stage_dev(self._h, int(stage), int(policy_seed), int(step), int(ms), words, out))
 
+    def rollout_launch(self, launches, steps_per_launch=1, policy_seed=0xD71, first_step=0, ms=400):
+        """The launches of rollout_random alone (what bench.py times).  -> elapsed_ms between HIP events around them."""
+        elapsed = C.c_float(0.0)
+        self._check(self.lib.tetris_rollout_launch(self._h, int(launches), int(steps_per_launch), int(policy_seed), int(first_step),
+                                                   int(ms), C.byref(elapsed)))
+        return float(elapsed.value)
+
     def rollout_totals(self):
-        """-> uint64 [3]: cumulative episodes, lines cleared, garbage lines sent of this batch's built-in rollouts."""
-        t = np.zeros(3, np.uint64)
+        """-> uint64 [4]: cumulative env-steps (counted on the device), episodes, lines cleared, garbage lines sent of this
+        batch's built-in rollouts."""
+        t = np.zeros(4, np.uint64)
         self._check(self.lib.tetris_rollout_totals(self._h, _p(t)))
         return t
 

@@ -198,7 +198,8 @@ struct Game {
     int round_over, last_winner;
     uint32_t flags;                  // split mode (cross-device opponents): side[0] opp_dead[1] split[2]
     uint32_t episode;
-    uint32_t roll_lines, roll_sent;  // cumulative rollout counters (G_LINES, G_SENT)
+    uint32_t steps;                  // G_STEPS (cumulative; loaded and stored by the built-in rollout only)
+    uint32_t add_lines, add_sent;    // this launch's additions to G_LINES / G_SENT (memory is touched only when non-zero)
     uint32_t status;                 // te::Status bits raised while stepping this game
     uint32_t draw0, draw1;           // rollout kernels: the synthetic policy's words for the NEXT step (registers only)
 };
@@ -250,26 +251,28 @@ TE_HD void load_player(const uint32_t* s, uint32_t o, size_t ws, Player& q, bool
     }
 }
 
-// the per-game words
+// the per-game words; `counters`: also G_STEPS (the built-in rollout)
 template <int P>
-TE_HD void load_game_words(const uint32_t* gstate, size_t n, size_t slot, Game<P>& g) {
-    const uint32_t o = (uint32_t)slot * 4u;
-    uint32_t meta = ldw(gstate, o, (size_t)G_META * n);
+TE_HD void load_game_words(const Ref& gr, Game<P>& g, bool counters = false) {
+    uint32_t meta = ldw(gr.s, gr.o, (size_t)G_META * gr.ws);
     g.seed16 = meta & 0xFFFFu;
     g.round_over = (meta >> 16) & 1;
     g.last_winner = (int)((meta >> 17) & 0xF) - 1;
     g.flags = (meta >> 21) & 7u;
-    g.episode = ldw(gstate, o, (size_t)G_EPISODE * n);
-    g.roll_lines = ldw(gstate, o, (size_t)G_LINES * n);
-    g.roll_sent = ldw(gstate, o, (size_t)G_SENT * n);
+    g.episode = ldw(gr.s, gr.o, (size_t)G_EPISODE * gr.ws);
+    g.steps = counters ? ldw(gr.s, gr.o, (size_t)G_STEPS * gr.ws) : 0u;
+    g.add_lines = 0; g.add_sent = 0;
     g.status = 0;
 }
 
 template <int P>
-TE_HD void load_game(const uint32_t* state, const uint32_t* gstate, size_t n, size_t slot, Game<P>& g, bool tint = false, bool queue = true) {
-    load_game_words<P>(gstate, n, slot, g);
+TE_HD void load_game(const Geo& geo, size_t slot, Game<P>& g, bool tint = false, bool queue = true, bool counters = false) {
+    load_game_words<P>(game_ref(geo, slot), g, counters);
     TE_UNROLL
-    for (int p = 0; p < P; p++) load_player(state + (size_t)p * n, (uint32_t)slot * 4u, (size_t)P * n, g.pl[p], tint, queue);
+    for (int p = 0; p < P; p++) {
+        const Ref r = board_ref(geo, p, slot);
+        load_player(r.s, r.o, r.ws, g.pl[p], tint, queue);
+    }
 }
 
 TE_HD void store_player(uint32_t* s, uint32_t o, size_t ws, const Player& q, bool tint, bool queue = true) {
@@ -305,19 +308,24 @@ TE_HD void store_player(uint32_t* s, uint32_t o, size_t ws, const Player& q, boo
 }
 
 template <int P>
-TE_HD void store_game_words(uint32_t* gstate, size_t n, size_t slot, const Game<P>& g) {
-    const uint32_t o = (uint32_t)slot * 4u;
-    stw(gstate, o, (size_t)G_META * n, g.seed16 | ((uint32_t)g.round_over << 16) | ((uint32_t)(g.last_winner + 1) << 17) | (g.flags << 21));
-    stw(gstate, o, (size_t)G_EPISODE * n, g.episode);
-    stw(gstate, o, (size_t)G_LINES * n, g.roll_lines);
-    stw(gstate, o, (size_t)G_SENT * n, g.roll_sent);
+TE_HD void store_game_words(const Ref& gr, const Game<P>& g, bool counters = false) {
+    stw(gr.s, gr.o, (size_t)G_META * gr.ws, g.seed16 | ((uint32_t)g.round_over << 16) | ((uint32_t)(g.last_winner + 1) << 17) | (g.flags << 21));
+    stw(gr.s, gr.o, (size_t)G_EPISODE * gr.ws, g.episode);
+    if (counters) stw(gr.s, gr.o, (size_t)G_STEPS * gr.ws, g.steps);
+    // lines are cleared / sent in a few steps per thousand under a random policy: these two words are read-modify-written
+    // only then (each game's words belong to one lane, so a plain update is enough)
+    if (g.add_lines) word_at(gr, G_LINES) += g.add_lines;
+    if (g.add_sent) word_at(gr, G_SENT) += g.add_sent;
 }
 
 template <int P>
-TE_HD void store_game(uint32_t* state, uint32_t* gstate, size_t n, size_t slot, const Game<P>& g, bool tint = false, bool queue = true) {
-    store_game_words<P>(gstate, n, slot, g);
+TE_HD void store_game(const Geo& geo, size_t slot, const Game<P>& g, bool tint = false, bool queue = true, bool counters = false) {
+    store_game_words<P>(game_ref(geo, slot), g, counters);
     TE_UNROLL
-    for (int p = 0; p < P; p++) store_player(state + (size_t)p * n, (uint32_t)slot * 4u, (size_t)P * n, g.pl[p], tint, queue);
+    for (int p = 0; p < P; p++) {
+        const Ref r = board_ref(geo, p, slot);
+        store_player(r.s, r.o, r.ws, g.pl[p], tint, queue);
+    }
 }
 
 // ---------------------------------------------------------------- board primitives
@@ -768,7 +776,7 @@ TE_HD void init_game(const Ctx& cx, Game<P>& g, uint32_t seed16) {
         q.reward = 0; q.inc_count = 0; q.combo_remaining = 0; q.dead = 0; q.next = 0; q.kind = 7; q.rot = 0;
         q.q_loaded = 1;
     }
-    g.episode = 0; g.roll_lines = 0; g.roll_sent = 0; g.status = 0; g.flags = 0;
+    g.episode = 0; g.steps = 0; g.add_lines = 0; g.add_sent = 0; g.status = 0; g.flags = 0;
     reset_game(cx, g, seed16);
     g.last_winner = -1;
 }

@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256) void k_game(KArgs a) {
     __shared__ __attribute__((aligned(16))) uint32_t s_shapes_all[4][SHAPE_WORDS];
     uint32_t* s_shapes = s_shapes_all[threadIdx.x >> 6];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool active = i < a.n;
+    const bool active = lane_active(a, i);
     LaneCounters cnt = {0, 0, 0, 0};                   // (per-lane sums feed the CPU test harness only)
     TE_STAMP(0); TE_STAMP_RT(1);
     const uint32_t shape_word = d_shape_table.s[threadIdx.x & 63];
@@ -53,18 +53,18 @@ __global__ __launch_bounds__(256) void k_game(KArgs a) {
     TE_STAMP(14); TE_STAMP_RT(15);
 }
 
-// Sums the per-game cumulative rollout counters (G_EPISODE, G_LINES, G_SENT): run once before and once
-// after a rollout call, outside its timed region, instead of any cross-lane reduction inside the step
+// Sums the per-game cumulative rollout counters (G_STEPS, G_EPISODE, G_LINES, G_SENT): run once before and once
+// after a rollout, outside its timed region, instead of any cross-lane reduction inside the step
 // kernel (4096 same-address atomics per launch cost ~28 us; a shuffle + LDS + read-modify-write tail
 // still ~1.2 us of a 8 us launch).
-__global__ __launch_bounds__(256) void k_totals(const uint32_t* gstate, int n_games, unsigned long long* out /*[3]*/) {
-    unsigned long long v[3] = {0, 0, 0};
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_games; i += gridDim.x * blockDim.x) {
-        unsigned long long t[3];
-        totals_of_game(gstate, n_games, i, t);
-        v[0] += t[0]; v[1] += t[1]; v[2] += t[2];
+__global__ __launch_bounds__(256) void k_totals(Geo geo, unsigned long long* out /*[4]*/) {
+    unsigned long long v[4] = {0, 0, 0, 0};
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < (int)geo.n_games; i += gridDim.x * blockDim.x) {
+        unsigned long long t[4];
+        totals_of_game(geo, i, t);
+        v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3];
     }
-    for (int k = 0; k < 3; k++) {
+    for (int k = 0; k < 4; k++) {
         for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_down(v[k], off);
         if ((threadIdx.x & 63) == 0 && v[k]) atomicAdd(&out[k], v[k]);
     }
@@ -84,21 +84,23 @@ __global__ __launch_bounds__(256) void k_duo(KArgs a) {
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int gi = wave * 32 + (lane & 31);
     const bool active = gi < a.n;
-    const size_t N = (size_t)a.n_games;
+    constexpr bool ROLL = MODE == M_ROLLOUT, AUTO = MODE == M_STEP_RT_AUTO;
+    const Geo geo = geo_of(a);
+    const Ref gr = game_ref(geo, (size_t)gi), br = board_ref(geo, side, (size_t)gi);
     Game<1> g;
     Player& q = g.pl[0];
     if (active) {
-        load_game_words<1>(a.gstate, N, (size_t)gi, g);
-        load_player(a.state, (uint32_t)(side * a.n_games + gi) * 4u, 2 * N, q, false);
-        if (MODE == M_ROLLOUT) policy_draw(a, (uint32_t)gi, a.first_step, g.draw0, g.draw1);   // under the loads (see game_load)
+        load_game_words<1>(gr, g, ROLL);
+        load_player(br.s, br.o, br.ws, q, false);
+        if (ROLL) policy_draw(a, (uint32_t)gi, a.first_step, g.draw0, g.draw1);   // under the loads (see game_load)
         else { g.draw0 = a.rot[gi]; g.draw1 = (uint32_t)a.trans[gi] | ((a.player ? (uint32_t)a.player[gi] : 0u) << 8); }
     }
     s_shapes[lane] = shape_word;
     __builtin_amdgcn_wave_barrier();
     Ctx cx = make_ctx(a, s_shapes, false);
     uint32_t my_lines = 0, my_sent = 0;
-    int done = 0;
-    const int n_steps = (MODE == M_ROLLOUT) ? a.steps : 1;
+    int done = 0, out_reward = 0, out_dead = 0;
+    const int n_steps = ROLL ? a.steps : 1;
     for (int s = 0; s < n_steps; s++) {
         int r = 0, t = 0, acting = 0;
         ResetPrefetch rpf;
@@ -107,13 +109,13 @@ __global__ __launch_bounds__(256) void k_duo(KArgs a) {
         Player pre;
         uint32_t wa = 0;
         if (active) {
-            if (MODE == M_ROLLOUT) {
+            if (ROLL) {
                 const unsigned long long step = a.first_step + (unsigned long long)s;
                 r = (int)(g.draw0 & 3u); t = (int)(g.draw1 % 10u); acting = (int)(step % 2ull);
-                prefetch_reset(cx, episode_seed(a.game_offset + (uint32_t)gi, g.episode + 1), rpf);
             } else {
                 r = (int)(g.draw0 & 3u); t = (int)(g.draw1 & 0xFFu); acting = (int)(g.draw1 >> 8);
             }
+            if (ROLL || AUTO) prefetch_reset(cx, episode_seed(a.game_offset + (uint32_t)gi, g.episode + 1), rpf);
             prefetch_next(cx, q, g.seed16, g.status);
             sent_start = q.lines_sent;
             // stage A
@@ -142,32 +144,34 @@ __global__ __launch_bounds__(256) void k_duo(KArgs a) {
             const int in = (side == 0 && !(opp_b & XW_DIED)) ? xw_sent(opp_b) : 0;
             g.flags = (uint32_t)side;
             done = split_finish(g, in, (opp_b & XW_DEAD_NOW) != 0);
-            if (MODE == M_ROLLOUT) {
+            out_reward = q.reward; out_dead = q.dead;                  // what the step reports: the state BEFORE an auto-reset
+            if (ROLL) {
+                g.steps++;
                 if (!q.dead) my_lines += (unsigned)q.reward;
                 my_sent += (q.lines_sent - sent_start) & 0xFFFFu;
-                if (done) {
-                    g.episode++;
-                    reset_split(cx, g, episode_seed(a.game_offset + (uint32_t)gi, g.episode));
-                }
-                if (s + 1 < n_steps) policy_draw(a, (uint32_t)gi, a.first_step + (unsigned long long)s + 1ull, g.draw0, g.draw1);
             }
+            if ((ROLL || AUTO) && done) {
+                g.episode++;
+                reset_split(cx, g, episode_seed(a.game_offset + (uint32_t)gi, g.episode));
+            }
+            if (ROLL && s + 1 < n_steps) policy_draw(a, (uint32_t)gi, a.first_step + (unsigned long long)s + 1ull, g.draw0, g.draw1);
         }
     }
     const uint32_t opp_lines = __shfl_xor(my_lines, 32), opp_sent = __shfl_xor(my_sent, 32);
     if (active) {
-        store_player(a.state, (uint32_t)(side * a.n_games + gi) * 4u, 2 * N, q, false);
-        if (MODE == M_STEP_RT) {
-            if (a.lines) a.lines[(size_t)side * a.n + gi] = (uint8_t)q.reward;
-            if (a.dead) a.dead[(size_t)side * a.n + gi] = (uint8_t)q.dead;
+        store_player(br.s, br.o, br.ws, q, false);
+        if (!ROLL) {
+            if (a.lines) a.lines[(size_t)side * a.n + gi] = (uint8_t)out_reward;
+            if (a.dead) a.dead[(size_t)side * a.n + gi] = (uint8_t)out_dead;
         }
         const uint32_t st = g.status | __shfl_xor(g.status, 32);
         if (side == 0) {
-            if (MODE == M_STEP_RT && a.done) a.done[gi] = (uint8_t)done;
+            if (!ROLL && a.done) a.done[gi] = (uint8_t)done;
             g.flags = 0;
-            g.roll_lines += my_lines + opp_lines;
-            g.roll_sent += my_sent + opp_sent;
-            store_game_words<1>(a.gstate, N, (size_t)gi, g);
-            if (st) atomicOr(a.status, st);
+            g.add_lines = my_lines + opp_lines;
+            g.add_sent = my_sent + opp_sent;
+            store_game_words<1>(gr, g, ROLL);
+            report_status(a, st);
         }
     }
 }
@@ -202,18 +206,17 @@ __global__ __launch_bounds__(256) void k_gen_chunk(uint32_t* mt, float* w, uint8
 }
 
 template <int P, bool TINT>
-__global__ __launch_bounds__(256) void k_observe(const uint32_t* state, const uint32_t* gstate, int n_games, int n,
-                                                 const int32_t* idx, int H, tetris_record* rec, uint8_t* round_over,
+__global__ __launch_bounds__(256) void k_observe(Geo geo, int n, const int32_t* idx, int H, tetris_record* rec, uint8_t* round_over,
                                                  int8_t* last_winner) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) observe_body<P, TINT>(state, gstate, n_games, i, idx, H, d_shape_table.s, rec, round_over, last_winner);
+    if (i < n) observe_body<P, TINT>(geo, i, idx, H, d_shape_table.s, rec, round_over, last_winner);
 }
 
 // Observation kernel: one lane reads its board's ten column words (coalesced SoA), expands them to H*10 bytes
 // in LDS; after a barrier the workgroup streams its 256 boards' planes out as ONE contiguous run of dwords, so the
 // uint8 rows leave the chip fully coalesced (a lane writing its own 200 bytes would not be).
 template <int P>
-__global__ __launch_bounds__(256) void k_observe_packed_bytes(const uint32_t* state, int n_games, int n, const int32_t* idx,
+__global__ __launch_bounds__(256) void k_observe_packed_bytes(Geo geo, int n, const int32_t* idx,
                                                         const uint8_t* player, int H, uint8_t* visual, uint8_t* vector,
                                                         uint8_t* piece) {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_cells[];      // 256 * H * 10 bytes
@@ -223,11 +226,11 @@ __global__ __launch_bounds__(256) void k_observe_packed_bytes(const uint32_t* st
     const int nb = (n - first < 256) ? n - first : 256;
     for (int sl = 0; sl < P; sl++) {
         if (i < n) {
-            const size_t slot = safe_slot(idx, i, n_games);
+            const size_t slot = safe_slot(idx, i, (int)geo.n_games);
             const int me = safe_player(player, i, P);
             const int p = (sl == 0) ? me : (P - 1 - me);
             uint8_t vec[12];
-            const int kind = observe_board(state, n_games, slot, P, p, H, s_cells + (size_t)threadIdx.x * cells, vec);
+            const int kind = observe_board(geo, slot, p, H, s_cells + (size_t)threadIdx.x * cells, vec);
             uint8_t* v = vector + ((size_t)sl * n + i) * 12;
             for (int k = 0; k < 12; k++) v[k] = vec[k];
             piece[(size_t)sl * n + i] = (uint8_t)kind;
@@ -251,7 +254,7 @@ __global__ __launch_bounds__(256) void k_observe_packed_bytes(const uint32_t* st
 // with a row stride of nw + 1 words (odd: conflict-free), instead of 200 byte writes per lane; the workgroup's tile then
 // leaves as coalesced dword stores.  The 12 vector bytes of a board leave as 3 dwords.
 template <int P, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void k_observe_packed(const uint32_t* state, int n_games, int n, const int32_t* idx,
+__global__ __launch_bounds__(BLOCK) void k_observe_packed(Geo geo, int n, const int32_t* idx,
                                                           const uint8_t* player, int H, uint8_t* visual, uint8_t* vector,
                                                           uint8_t* piece, uint32_t inv_nw) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_words[];      // BLOCK * (nw + 1) words
@@ -261,14 +264,13 @@ __global__ __launch_bounds__(BLOCK) void k_observe_packed(const uint32_t* state,
     const int nb = (n - first < BLOCK) ? n - first : BLOCK;
     for (int sl = 0; sl < P; sl++) {
         if (i < n) {
-            const size_t slot = safe_slot(idx, i, n_games);
+            const size_t slot = safe_slot(idx, i, (int)geo.n_games);
             const int me = safe_player(player, i, P);
             const int p = (sl == 0) ? me : (P - 1 - me);
-            const size_t ws = (size_t)P * n_games;
-            const uint32_t* s = state + (size_t)p * n_games + slot;
+            const Ref br = board_ref(geo, p, slot);
             uint32_t col[NCOL];
-            for (int c = 0; c < NCOL; c++) col[c] = s[(size_t)(W_COL0 + c) * ws];
-            const uint32_t w = s[(size_t)W_PIECE * ws], m = s[(size_t)W_MISC * ws], dc = s[(size_t)W_DROPCOMBO * ws];
+            for (int c = 0; c < NCOL; c++) col[c] = word_at(br, W_COL0 + c);
+            const uint32_t w = word_at(br, W_PIECE), m = word_at(br, W_MISC), dc = word_at(br, W_DROPCOMBO);
             uint32_t* row = s_words + (size_t)threadIdx.x * pitch;
             for (int yp = 0; yp < H / 2; yp++) {
                 uint32_t lo[NCOL], hi[NCOL];                 // cells of rows 2 yp and 2 yp + 1
@@ -302,32 +304,30 @@ __global__ __launch_bounds__(BLOCK) void k_observe_packed(const uint32_t* state,
 }
 
 template <int P>
-__global__ __launch_bounds__(256) void k_enumerate(const uint32_t* state, int n_games, int n, const int32_t* idx,
+__global__ __launch_bounds__(256) void k_enumerate(Geo geo, int n, const int32_t* idx,
                                                    const uint8_t* player, int H, uint8_t* valid, int8_t* land_y,
                                                    uint8_t* cleared, uint32_t* after) {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < (size_t)n * 40) enumerate_body<P>(state, n_games, t, idx, player, H, d_shape_table.s, valid, land_y, cleared, after, t);
+    if (t < (size_t)n * 40) enumerate_body<P>(geo, t, idx, player, H, d_shape_table.s, valid, land_y, cleared, after, t);
 }
 
 template <int P>
-__global__ __launch_bounds__(64) void k_actions(const uint32_t* state, int n_games, int n, const int32_t* idx, const uint8_t* player,
+__global__ __launch_bounds__(64) void k_actions(Geo geo, int n, const int32_t* idx, const uint8_t* player,
                                                 int H, uint8_t* count, uint8_t* lens, uint8_t* keys, int max_lists, int max_keys,
                                                 uint32_t* status) {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t < (size_t)n * 40)
-        actions_body<P>(state, n_games, t, idx, player, H, d_shape_table.s, count, lens, keys, max_lists, max_keys, status);
+        actions_body<P>(geo, t, idx, player, H, d_shape_table.s, count, lens, keys, max_lists, max_keys, status);
 }
 
-__global__ __launch_bounds__(256) void k_snapshot(uint32_t* state, uint32_t* gstate, int n_games, int n, const int32_t* idx,
-                                                  int P, uint32_t* blob, int restore, int nw) {
+__global__ __launch_bounds__(256) void k_snapshot(Geo geo, int n, const int32_t* idx, uint32_t* blob, int restore) {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < (size_t)n * (NGWORDS + P * nw)) snapshot_body(state, gstate, n_games, t, idx, P, blob, restore, nw);
+    if (t < (size_t)n * (NGWORDS + geo.P * geo.nw)) snapshot_body(geo, t, idx, blob, restore);
 }
 
-__global__ __launch_bounds__(256) void k_set_dead(uint32_t* state, int n_games, int n, const int32_t* idx, int P,
-                                                  const uint8_t* dead /*[n][P]*/) {
+__global__ __launch_bounds__(256) void k_set_dead(Geo geo, int n, const int32_t* idx, const uint8_t* dead /*[n][P]*/) {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < n * P) set_dead_body(state, n_games, t, idx, P, dead);
+    if (t < n * geo.P) set_dead_body(geo, t, idx, dead);
 }
 
 // ============================================================================ host side
@@ -466,39 +466,52 @@ struct tetris_batch {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     uint32_t* d_state = nullptr;
     uint32_t* d_gstate = nullptr;
-    uint32_t* d_status = nullptr;        // [0] sticky te::Status bits
+    uint32_t* flags = nullptr;           // te::Flag words: pinned, host-coherent, written by kernels with plain stores
     unsigned long long* d_counters = nullptr;
-    uint32_t* h_status = nullptr;        // pinned
+    unsigned long long* h_counters = nullptr;   // pinned [8]
     Tables* tab = nullptr;
-    uint32_t margin = 64;
+    uint32_t margin = 192;               // low-water mark of the RNG tables (draws); covers the launches in flight (gate below)
     uint32_t game_offset = 0;
     int split = 0, side = 0;
     int tint = 0, nw = NWORDS;           // colour planes tracked; words per player-board
     int use_duo = 1;                     // two-player rollout / step_rt through k_duo (TETRIS_NO_DUO=1 in the environment: k_game<2>)
     uint32_t* d_shadow = nullptr;        // split mode, side 1
     hipStream_t own_stream = nullptr;
+    // Run-ahead gate of the asynchronous entry points: every GATE_GROUP launches an event is recorded; before a new group is
+    // enqueued the host waits for the event of the group before the previous one.  At most 2 * GATE_GROUP + 1 launches are
+    // therefore in flight whose flag words the host has not seen; `margin` is sized for that many steps.
+    hipEvent_t gate_ev[2] = {nullptr, nullptr};
+    int gate_count = 0;                  // launches since the last recorded event
+    int gate_slot = 0;                   // event to record next
+    int gate_pending[2] = {0, 0};        // event has been recorded and not waited for
     Stage s_idx, s_in0, s_in1, s_in2, s_out0, s_out1, s_out2, s_big, s_act0, s_act1, s_act2;
 };
+static constexpr int GATE_GROUP = 32;
+
+static Geo geo_of_batch(tetris_batch* b) {
+    Geo g = {b->d_state, b->d_gstate, (size_t)b->N, b->P, b->nw};
+    return g;
+}
 
 static KArgs base_args(tetris_batch* b, int n, const int32_t* d_idx) {
     KArgs a;
     memset(&a, 0, sizeof a);
-    a.state = b->d_state; a.gstate = b->d_gstate; a.status = b->d_status;
+    a.state = b->d_state; a.gstate = b->d_gstate; a.status = b->flags;
     {   // tables are shared between batches: take pointer and size together (another batch may be growing them)
         std::lock_guard<std::mutex> lock(g_tab_mutex);
         a.table = b->tab->d_table;
         a.n_draws = (uint32_t)b->tab->n_chunks * CHUNK;
     }
     a.start = b->tab->d_start; a.combo_pow = b->tab->d_pow; a.margin = b->margin;
-    a.H = b->H; a.n_games = b->N; a.n = n; a.idx = d_idx; a.game_offset = b->game_offset;
+    a.H = b->H; a.n_games = b->N; a.n_players = b->P; a.nw = b->nw; a.n = n; a.idx = d_idx; a.game_offset = b->game_offset;
     return a;
 }
 
 template <int MODE>
 static int launch_game(tetris_batch* b, const KArgs& a) {
     dim3 grid((unsigned)((a.n + 255) / 256)), block(256);
-    if constexpr (MODE == M_ROLLOUT || MODE == M_STEP_RT) {
-        if (b->P == 2 && !b->tint && !a.idx && b->use_duo && (MODE == M_STEP_RT || a.steps == 1)) {
+    if constexpr (MODE == M_ROLLOUT || MODE == M_STEP_RT || MODE == M_STEP_RT_AUTO) {
+        if (b->P == 2 && !b->tint && !a.idx && b->use_duo && (MODE != M_ROLLOUT || a.steps == 1)) {
             // two-player full-batch single steps: players in adjacent half-waves (k_duo), 32 games per wave.  Measured on
             // MI355X at 64k games: 9.37 us vs 9.73 us for k_game<2> at one step per launch, but 4.4 vs 3.9 us per step when
             // 16 steps are fused, so fused rollouts stay on k_game<2>.
@@ -515,24 +528,51 @@ static int launch_game(tetris_batch* b, const KArgs& a) {
     return TETRIS_OK;
 }
 
-// drain + read the sticky status word; extend the RNG tables when a board came close to their end
-static int finish_call(tetris_batch* b) {
-    HIP_TRY(hipMemcpyAsync(b->h_status, b->d_status, 4, hipMemcpyDeviceToHost, b->stream));
-    HIP_TRY(hipStreamSynchronize(b->stream));
-    uint32_t st = *b->h_status;
-    if (st & ST_STREAM_EXHAUSTED) return fail(TETRIS_E_STREAM, "an episode ran past the RNG tables; state is invalid");
-    if (st & ST_FIFO_OVERFLOW) return fail(TETRIS_E_FIFO, "garbage FIFO overflow (> 8 pending packets); state is invalid");
-    if (st & ST_BAD_ARGUMENT) {
-        HIP_TRY(hipMemsetAsync(b->d_status, 0, 4, b->stream));
-        HIP_TRY(hipStreamSynchronize(b->stream));
-        return fail(TETRIS_E_ARG, "output capacity exceeded (max_lists / max_keys too small)");
-    }
-    if (st & ST_NEED_EXTEND) {
+// Looks at the flag words WITHOUT enqueuing or waiting for anything: answers a pending "extend the RNG tables" request
+// (the generation kernel goes on the batch's stream, i.e. before every launch made after this call).
+static int service_flags(tetris_batch* b) {
+    volatile uint32_t* f = b->flags;
+    const uint32_t want = f[F_EXTEND];
+    if (want) {
         std::lock_guard<std::mutex> lock(g_tab_mutex);
-        int rc = tables_extend(b->tab, b->stream);
-        if (rc) return rc;
-        HIP_TRY(hipMemsetAsync(b->d_status, 0, 4, b->stream));
-        HIP_TRY(hipStreamSynchronize(b->stream));
+        if (want >= (uint32_t)b->tab->n_chunks * CHUNK) {        // not yet answered (requests carry the size their kernel saw)
+            int rc = tables_extend(b->tab, b->stream);
+            if (rc) return rc;
+        }
+        f[F_EXTEND] = 0;
+    }
+    return TETRIS_OK;
+}
+
+// One more asynchronous launch is about to be enqueued: bound the run-ahead (see tetris_batch) and service the flags.
+static int gate_launch(tetris_batch* b, int group = GATE_GROUP) {
+    if (b->gate_count >= group) {
+        const int k = b->gate_slot;
+        if (b->gate_pending[k]) {                               // the group before the previous one must have finished
+            HIP_TRY(hipEventSynchronize(b->gate_ev[k]));
+            b->gate_pending[k] = 0;
+        }
+        HIP_TRY(hipEventRecord(b->gate_ev[k], b->stream));
+        b->gate_pending[k] = 1;
+        b->gate_slot = k ^ 1;
+        b->gate_count = 0;
+    }
+    b->gate_count++;
+    return service_flags(b);
+}
+
+// drain the stream, then the flag words: sticky errors surface, the RNG tables are extended when a board came close to their end
+static int finish_call(tetris_batch* b) {
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    b->gate_count = 0; b->gate_pending[0] = b->gate_pending[1] = 0;
+    volatile uint32_t* f = b->flags;
+    if (f[F_EXHAUSTED]) return fail(TETRIS_E_STREAM, "an episode ran past the RNG tables; state is invalid");
+    if (f[F_FIFO]) return fail(TETRIS_E_FIFO, "garbage FIFO overflow (> 8 pending packets); state is invalid");
+    int rc = service_flags(b);                                  // before the argument error below: an extend request is never dropped
+    if (rc) return rc;
+    if (f[F_BADARG]) {
+        f[F_BADARG] = 0;
+        return fail(TETRIS_E_ARG, "output capacity exceeded (max_lists / max_keys too small)");
     }
     return TETRIS_OK;
 }
@@ -598,8 +638,10 @@ int tetris_destroy(tetris_batch* b) {
     (void)hipSetDevice(b->device);
     if (b->stream) (void)hipStreamSynchronize(b->stream);
     if (b->tab) tables_release(b->tab);
-    (void)hipFree(b->d_shadow); (void)hipFree(b->d_state); (void)hipFree(b->d_gstate); (void)hipFree(b->d_status); (void)hipFree(b->d_counters);
-    if (b->h_status) (void)hipHostFree(b->h_status);
+    (void)hipFree(b->d_shadow); (void)hipFree(b->d_state); (void)hipFree(b->d_gstate); (void)hipFree(b->d_counters);
+    if (b->flags) (void)hipHostFree(b->flags);
+    if (b->h_counters) (void)hipHostFree(b->h_counters);
+    for (hipEvent_t e : b->gate_ev) if (e) (void)hipEventDestroy(e);
     Stage* all[] = {&b->s_idx, &b->s_in0, &b->s_in1, &b->s_in2, &b->s_out0, &b->s_out1, &b->s_out2, &b->s_big, &b->s_act0, &b->s_act1, &b->s_act2};
     for (Stage* s : all) s->release();
     if (b->ev0) (void)hipEventDestroy(b->ev0);
@@ -647,14 +689,18 @@ static int create_impl(tetris_batch** out, int n_games, int n_players, int heigh
     b->own_stream = b->stream;
     CREATE_TRY(hipEventCreate(&b->ev0));
     CREATE_TRY(hipEventCreate(&b->ev1));
-    CREATE_TRY(hipMalloc((void**)&b->d_state, (size_t)b->nw * n_players * n_games * 4));
-    CREATE_TRY(hipMalloc((void**)&b->d_gstate, (size_t)NGWORDS * n_games * 4));
-    CREATE_TRY(hipMalloc((void**)&b->d_status, 16));
+    CREATE_TRY(hipEventCreateWithFlags(&b->gate_ev[0], hipEventDisableTiming));
+    CREATE_TRY(hipEventCreateWithFlags(&b->gate_ev[1], hipEventDisableTiming));
+    const size_t state_bytes = state_words((size_t)n_games, n_players, b->nw) * 4, gstate_bytes = gstate_words((size_t)n_games) * 4;
+    CREATE_TRY(hipMalloc((void**)&b->d_state, state_bytes));
+    CREATE_TRY(hipMalloc((void**)&b->d_gstate, gstate_bytes));
     CREATE_TRY(hipMalloc((void**)&b->d_counters, 8 * sizeof(unsigned long long)));
-    CREATE_TRY(hipHostMalloc((void**)&b->h_status, 128, hipHostMallocDefault));
-    CREATE_TRY(hipMemsetAsync(b->d_status, 0, 16, b->stream));
-    CREATE_TRY(hipMemsetAsync(b->d_gstate, 0, (size_t)NGWORDS * n_games * 4, b->stream));
-    CREATE_TRY(hipMemsetAsync(b->d_state, 0, (size_t)b->nw * n_players * n_games * 4, b->stream));
+    CREATE_TRY(hipHostMalloc((void**)&b->h_counters, 8 * sizeof(unsigned long long), hipHostMallocDefault));
+    // flag words: host memory the GPU can write (fine-grained, so a store is visible to the host while the kernel runs)
+    CREATE_TRY(hipHostMalloc((void**)&b->flags, NFLAGS * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent));
+    memset(b->flags, 0, NFLAGS * sizeof(uint32_t));
+    CREATE_TRY(hipMemsetAsync(b->d_gstate, 0, gstate_bytes, b->stream));
+    CREATE_TRY(hipMemsetAsync(b->d_state, 0, state_bytes, b->stream));
     int rc = tables_acquire(&b->tab, device, piece_map, b->stream);
     if (rc) { std::string keep = g_err; tetris_destroy(b); return fail(rc, keep); }
     const int16_t* d_seeds = nullptr;
@@ -664,7 +710,7 @@ static int create_impl(tetris_batch** out, int n_games, int n_players, int heigh
         d_seeds = (const int16_t*)b->s_in0.d;
     }
     b->split = split; b->side = side;
-    if (split && side == 1) CREATE_TRY(hipMalloc((void**)&b->d_shadow, (size_t)b->nw * n_players * n_games * 4));
+    if (split && side == 1) CREATE_TRY(hipMalloc((void**)&b->d_shadow, state_bytes));
     KArgs a = base_args(b, n_games, nullptr);
     a.seeds = d_seeds;
     a.steps = side;
@@ -745,19 +791,17 @@ int tetris_split_rollout_stage_dev(tetris_batch* b, int stage, uint32_t policy_s
     return TETRIS_OK;
 }
 
-int tetris_rollout_totals(tetris_batch* b, uint64_t totals[3]) {
+int tetris_rollout_totals(tetris_batch* b, uint64_t totals[4]) {
     int rc = check_batch(b);
     if (rc) return rc;
     if (!totals) return fail(TETRIS_E_ARG, "totals is NULL");
     HIP_TRY(hipMemsetAsync(b->d_counters, 0, 8 * sizeof(unsigned long long), b->stream));
     const int tot_blocks = b->N >= 65536 ? 64 : (b->N + 1023) / 1024;
-    hipLaunchKernelGGL(k_totals, dim3(tot_blocks), dim3(256), 0, b->stream, b->d_gstate, b->N, b->d_counters);
+    hipLaunchKernelGGL(k_totals, dim3(tot_blocks), dim3(256), 0, b->stream, geo_of_batch(b), b->d_counters);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(b->h_status + 2, b->d_counters, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipMemcpyAsync(b->h_counters, b->d_counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, b->stream));
     if ((rc = finish_call(b))) return rc;
-    unsigned long long hc[3];
-    memcpy(hc, b->h_status + 2, sizeof hc);
-    for (int k = 0; k < 3; k++) totals[k] = hc[k];
+    for (int k = 0; k < 4; k++) totals[k] = b->h_counters[k];
     return TETRIS_OK;
 }
 
@@ -772,7 +816,7 @@ int tetris_reset(tetris_batch* b, const int32_t* idx, int n, const int16_t* seed
     if (rc) return rc;
     const int32_t* d_idx;
     if ((rc = stage_idx(b, idx, n, &d_idx))) return rc;
-    if (n == 0) return TETRIS_OK;
+    if (n == 0) return finish_call(b);          // still a synchronisation point: sticky errors surface, tables get extended
     KArgs a = base_args(b, n, d_idx);
     if (seeds) {
         if ((rc = stage_in(b, b->s_in0, seeds, (size_t)n * 2))) return rc;
@@ -883,15 +927,33 @@ int tetris_step_keys(tetris_batch* b, const int32_t* idx, int n, const uint8_t* 
     return fetch_outputs(b, n, done, lines, dead);
 }
 
-int tetris_step_rt_dev(tetris_batch* b, const uint8_t* d_rot, const uint8_t* d_trans, const uint8_t* d_player, int ms,
-                       uint8_t* d_done, uint8_t* d_lines, uint8_t* d_dead) {
+int tetris_step_rt_dev_ex(tetris_batch* b, const uint8_t* d_rot, const uint8_t* d_trans, const uint8_t* d_player, int ms,
+                          uint8_t* d_done, uint8_t* d_lines, uint8_t* d_dead, int flags) {
     int rc = check_batch(b);
     if (rc) return rc;
     if (!d_rot || !d_trans) return fail(TETRIS_E_ARG, "rot/trans are NULL");
+    if (flags & ~TETRIS_STEP_AUTO_RESET) return fail(TETRIS_E_ARG, "unknown flag");
+    if ((flags & TETRIS_STEP_AUTO_RESET) && b->split) return fail(TETRIS_E_ARG, "auto-reset is not available on split batches");
+    if ((rc = gate_launch(b))) return rc;
     KArgs a = base_args(b, b->N, nullptr);
     a.rot = d_rot; a.trans = d_trans; a.player = d_player; a.ms = ms;
     a.done = d_done; a.lines = d_lines; a.dead = d_dead;
-    return launch_game<M_STEP_RT>(b, a);
+    return (flags & TETRIS_STEP_AUTO_RESET) ? launch_game<M_STEP_RT_AUTO>(b, a) : launch_game<M_STEP_RT>(b, a);
+}
+
+int tetris_step_rt_dev(tetris_batch* b, const uint8_t* d_rot, const uint8_t* d_trans, const uint8_t* d_player, int ms,
+                       uint8_t* d_done, uint8_t* d_lines, uint8_t* d_dead) {
+    return tetris_step_rt_dev_ex(b, d_rot, d_trans, d_player, ms, d_done, d_lines, d_dead, 0);
+}
+
+int tetris_reset_dev(tetris_batch* b, const uint8_t* d_mask, const int16_t* d_seeds) {
+    int rc = check_batch(b);
+    if (rc) return rc;
+    if (b->split) return fail(TETRIS_E_ARG, "tetris_reset_dev is not available on split batches");
+    if ((rc = gate_launch(b))) return rc;
+    KArgs a = base_args(b, b->N, nullptr);
+    a.mask = d_mask; a.seeds = d_seeds;
+    return d_seeds ? launch_game<M_RESET>(b, a) : launch_game<M_RESET_SCHED>(b, a);
 }
 
 int tetris_step_rt(tetris_batch* b, const uint8_t* rot, const uint8_t* trans, const uint8_t* player, int ms, uint8_t* done,
@@ -932,7 +994,7 @@ int tetris_observe_records(tetris_batch* b, const int32_t* idx, int n, tetris_re
     tetris_record* d_rec = (tetris_record*)b->s_big.d;
     HIP_TRY(hipMemsetAsync(d_rec, 0, rec_bytes, b->stream));      // struct padding stays deterministic
 #define LAUNCH_OBSERVE(PP, TT)                                                                                              \
-    hipLaunchKernelGGL((k_observe<PP, TT>), grid, block, 0, b->stream, b->d_state, b->d_gstate, b->N, n, d_idx, b->H, d_rec, \
+    hipLaunchKernelGGL((k_observe<PP, TT>), grid, block, 0, b->stream, geo_of_batch(b), n, d_idx, b->H, d_rec, \
                        (uint8_t*)b->s_out0.d, (int8_t*)b->s_out1.d)
     if (b->P == 1 && !b->tint) LAUNCH_OBSERVE(1, false);
     else if (b->P == 1) LAUNCH_OBSERVE(1, true);
@@ -966,10 +1028,10 @@ int tetris_observe_packed_dev(tetris_batch* b, const int32_t* d_idx, int n, cons
         const uint32_t inv_nw = (uint32_t)(((1ull << 32) + (uint64_t)nw - 1) / (uint64_t)nw);
         dim3 ogrid((unsigned)((n + OB - 1) / OB)), oblock(OB);
         if (b->P == 1)
-            hipLaunchKernelGGL((k_observe_packed<1, OB>), ogrid, oblock, lds, b->stream, b->d_state, b->N, n, d_idx, d_player, b->H,
+            hipLaunchKernelGGL((k_observe_packed<1, OB>), ogrid, oblock, lds, b->stream, geo_of_batch(b), n, d_idx, d_player, b->H,
                                d_visual, d_vector, d_piece, inv_nw);
         else
-            hipLaunchKernelGGL((k_observe_packed<2, OB>), ogrid, oblock, lds, b->stream, b->d_state, b->N, n, d_idx, d_player, b->H,
+            hipLaunchKernelGGL((k_observe_packed<2, OB>), ogrid, oblock, lds, b->stream, geo_of_batch(b), n, d_idx, d_player, b->H,
                                d_visual, d_vector, d_piece, inv_nw);
         HIP_TRY(hipGetLastError());
         return TETRIS_OK;
@@ -980,10 +1042,10 @@ int tetris_observe_packed_dev(tetris_batch* b, const int32_t* d_idx, int n, cons
         HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
     if (b->P == 1)
-        hipLaunchKernelGGL(k_observe_packed_bytes<1>, grid, block, lds, b->stream, b->d_state, b->N, n, d_idx, d_player, b->H, d_visual,
+        hipLaunchKernelGGL(k_observe_packed_bytes<1>, grid, block, lds, b->stream, geo_of_batch(b), n, d_idx, d_player, b->H, d_visual,
                            d_vector, d_piece);
     else
-        hipLaunchKernelGGL(k_observe_packed_bytes<2>, grid, block, lds, b->stream, b->d_state, b->N, n, d_idx, d_player, b->H, d_visual,
+        hipLaunchKernelGGL(k_observe_packed_bytes<2>, grid, block, lds, b->stream, geo_of_batch(b), n, d_idx, d_player, b->H, d_visual,
                            d_vector, d_piece);
     HIP_TRY(hipGetLastError());
     return TETRIS_OK;
@@ -1030,8 +1092,8 @@ static int snapshot_impl(tetris_batch* b, const int32_t* idx, int n, uint32_t* b
         HIP_TRY(hipMemcpyAsync(b->s_big.d, b->s_big.h, bytes, hipMemcpyHostToDevice, b->stream));
     }
     size_t total = (size_t)n * words;
-    hipLaunchKernelGGL(k_snapshot, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, b->stream, b->d_state, b->d_gstate,
-                       b->N, n, d_idx, b->P, (uint32_t*)b->s_big.d, restore, b->nw);
+    hipLaunchKernelGGL(k_snapshot, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, b->stream, geo_of_batch(b), n, d_idx,
+                       (uint32_t*)b->s_big.d, restore);
     HIP_TRY(hipGetLastError());
     if (!restore) HIP_TRY(hipMemcpyAsync(b->s_big.h, b->s_big.d, bytes, hipMemcpyDeviceToHost, b->stream));
     if ((rc = finish_call(b))) return rc;
@@ -1052,8 +1114,8 @@ int tetris_set_dead(tetris_batch* b, const int32_t* idx, int n, const uint8_t* d
     if ((rc = stage_idx(b, idx, n, &d_idx))) return rc;
     if (n == 0) return TETRIS_OK;
     if ((rc = stage_in(b, b->s_in0, dead, (size_t)n * b->P))) return rc;
-    hipLaunchKernelGGL(k_set_dead, dim3((unsigned)((n * b->P + 255) / 256)), dim3(256), 0, b->stream, b->d_state, b->N, n,
-                       d_idx, b->P, (const uint8_t*)b->s_in0.d);
+    hipLaunchKernelGGL(k_set_dead, dim3((unsigned)((n * b->P + 255) / 256)), dim3(256), 0, b->stream, geo_of_batch(b), n, d_idx,
+                       (const uint8_t*)b->s_in0.d);
     HIP_TRY(hipGetLastError());
     return finish_call(b);
 }
@@ -1081,10 +1143,10 @@ int tetris_enumerate_drops(tetris_batch* b, const int32_t* idx, int n, const uin
     uint32_t* d_after = after ? (uint32_t*)b->s_big.d : nullptr;
     dim3 grid((unsigned)((lanes + 255) / 256)), block(256);
     if (b->P == 1)
-        hipLaunchKernelGGL(k_enumerate<1>, grid, block, 0, b->stream, b->d_state, b->N, n, d_idx, d_player, b->H,
+        hipLaunchKernelGGL(k_enumerate<1>, grid, block, 0, b->stream, geo_of_batch(b), n, d_idx, d_player, b->H,
                            (uint8_t*)b->s_out0.d, (int8_t*)b->s_out1.d, (uint8_t*)b->s_out2.d, d_after);
     else
-        hipLaunchKernelGGL(k_enumerate<2>, grid, block, 0, b->stream, b->d_state, b->N, n, d_idx, d_player, b->H,
+        hipLaunchKernelGGL(k_enumerate<2>, grid, block, 0, b->stream, geo_of_batch(b), n, d_idx, d_player, b->H,
                            (uint8_t*)b->s_out0.d, (int8_t*)b->s_out1.d, (uint8_t*)b->s_out2.d, d_after);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(b->s_out0.h, b->s_out0.d, lanes, hipMemcpyDeviceToHost, b->stream));
@@ -1107,10 +1169,10 @@ int tetris_enumerate_drops_dev(tetris_batch* b, const int32_t* d_idx, int n, con
     const size_t lanes = (size_t)n * 40;
     dim3 grid((unsigned)((lanes + 255) / 256)), block(256);
     if (b->P == 1)
-        hipLaunchKernelGGL(k_enumerate<1>, grid, block, 0, b->stream, b->d_state, b->N, n, d_idx, d_player, b->H, d_valid, d_land_y,
+        hipLaunchKernelGGL(k_enumerate<1>, grid, block, 0, b->stream, geo_of_batch(b), n, d_idx, d_player, b->H, d_valid, d_land_y,
                            d_cleared, d_after);
     else
-        hipLaunchKernelGGL(k_enumerate<2>, grid, block, 0, b->stream, b->d_state, b->N, n, d_idx, d_player, b->H, d_valid, d_land_y,
+        hipLaunchKernelGGL(k_enumerate<2>, grid, block, 0, b->stream, geo_of_batch(b), n, d_idx, d_player, b->H, d_valid, d_land_y,
                            d_cleared, d_after);
     HIP_TRY(hipGetLastError());
     return TETRIS_OK;
@@ -1163,11 +1225,11 @@ int tetris_get_actions(tetris_batch* b, const int32_t* idx, int n, const uint8_t
             (rc = s_key.ensure(lanes * LANE_LISTS * max_keys + 4))) { result = rc; break; }
         dim3 grid((unsigned)((lanes + 63) / 64)), block(64);
         if (b->P == 1)
-            hipLaunchKernelGGL(k_actions<1>, grid, block, 0, b->stream, b->d_state, b->N, m, d_idx, d_player, b->H, (uint8_t*)s_cnt.d,
-                               (uint8_t*)s_len.d, (uint8_t*)s_key.d, LANE_LISTS, max_keys, b->d_status);
+            hipLaunchKernelGGL(k_actions<1>, grid, block, 0, b->stream, geo_of_batch(b), m, d_idx, d_player, b->H, (uint8_t*)s_cnt.d,
+                               (uint8_t*)s_len.d, (uint8_t*)s_key.d, LANE_LISTS, max_keys, b->flags);
         else
-            hipLaunchKernelGGL(k_actions<2>, grid, block, 0, b->stream, b->d_state, b->N, m, d_idx, d_player, b->H, (uint8_t*)s_cnt.d,
-                               (uint8_t*)s_len.d, (uint8_t*)s_key.d, LANE_LISTS, max_keys, b->d_status);
+            hipLaunchKernelGGL(k_actions<2>, grid, block, 0, b->stream, geo_of_batch(b), m, d_idx, d_player, b->H, (uint8_t*)s_cnt.d,
+                               (uint8_t*)s_len.d, (uint8_t*)s_key.d, LANE_LISTS, max_keys, b->flags);
         if (hipGetLastError() != hipSuccess) { result = fail(TETRIS_E_HIP, "k_actions launch failed"); break; }
         (void)hipMemcpyAsync(s_cnt.h, s_cnt.d, lanes, hipMemcpyDeviceToHost, b->stream);
         (void)hipMemcpyAsync(s_len.h, s_len.d, lanes * LANE_LISTS, hipMemcpyDeviceToHost, b->stream);
@@ -1195,49 +1257,49 @@ int tetris_get_actions(tetris_batch* b, const int32_t* idx, int n, const uint8_t
     return result;
 }
 
-int tetris_rollout_random(tetris_batch* b, int launches, int steps_per_launch, uint32_t policy_seed, uint64_t first_step,
-                          int ms, uint64_t counters[4], float* elapsed_ms) {
+int tetris_rollout_launch(tetris_batch* b, int launches, int steps_per_launch, uint32_t policy_seed, uint64_t first_step,
+                          int ms, float* elapsed_ms) {
     int rc = check_batch(b);
     if (rc) return rc;
     if (launches < 1 || steps_per_launch < 0) return fail(TETRIS_E_ARG, "launches must be >= 1, steps_per_launch >= 0");
-    // A launch may consume 2 piece draws per step and player, and the host only looks at the status
-    // word between groups of launches: keep each group <= 256 env-steps and the low-water margin
-    // above what one group can consume, so the tables are always extended in time.
     if (steps_per_launch > 256) return fail(TETRIS_E_ARG, "steps_per_launch must be <= 256");
-    const int group = steps_per_launch ? 256 / steps_per_launch : 256;   // 0 = load/store only (diagnostic floor)
+    // A step may consume 2 piece draws per player, and the host learns of a board that came close to the end of the RNG
+    // tables only through the flag words, up to 2 * GATE_GROUP + 1 launches late (gate_launch): the low-water margin
+    // covers what those launches can consume.  Nothing in this loop waits for the GPU unless the host runs that far ahead.
     const uint32_t saved_margin = b->margin;
-    b->margin = (uint32_t)(2 * group * steps_per_launch + 16);
-    if (b->margin < saved_margin) b->margin = saved_margin;
-    // totals before (d_counters[0..2]) and after (d_counters[4..6]) the launches, outside the timed region
-    HIP_TRY(hipMemsetAsync(b->d_counters, 0, 8 * sizeof(unsigned long long), b->stream));
-    const int tot_blocks = b->N >= 65536 ? 64 : (b->N + 1023) / 1024;
-    hipLaunchKernelGGL(k_totals, dim3(tot_blocks), dim3(256), 0, b->stream, b->d_gstate, b->N, b->d_counters);
-    HIP_TRY(hipGetLastError());
+    struct MarginGuard {                          // every return path below puts the margin back
+        tetris_batch* b; uint32_t saved;
+        ~MarginGuard() { b->margin = saved; }
+    } margin_guard{b, saved_margin};
+    int group = steps_per_launch ? 64 / steps_per_launch : GATE_GROUP;       // fused launches: fewer of them in flight
+    group = group < 1 ? 1 : (group > GATE_GROUP ? GATE_GROUP : group);
+    const uint32_t need = (uint32_t)(2 * steps_per_launch * (2 * group + 2) + 16);
+    if (b->margin < need) b->margin = need;
     HIP_TRY(hipEventRecord(b->ev0, b->stream));
     for (int l = 0; l < launches; l++) {
+        if ((rc = gate_launch(b, group))) return rc;
         KArgs a = base_args(b, b->N, nullptr);
         a.ms = ms; a.steps = steps_per_launch; a.policy_seed = policy_seed;
         a.first_step = first_step + (uint64_t)l * (uint64_t)steps_per_launch;
-        if ((rc = launch_game<M_ROLLOUT>(b, a))) { b->margin = saved_margin; return rc; }
-        if ((l + 1) % group == 0 && l + 1 < launches)
-            if ((rc = finish_call(b))) { b->margin = saved_margin; return rc; }
+        if ((rc = launch_game<M_ROLLOUT>(b, a))) return rc;
     }
     HIP_TRY(hipEventRecord(b->ev1, b->stream));
-    hipLaunchKernelGGL(k_totals, dim3(tot_blocks), dim3(256), 0, b->stream, b->d_gstate, b->N, b->d_counters + 4);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(b->h_status + 2, b->d_counters, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, b->stream));
-    rc = finish_call(b);
-    b->margin = saved_margin;
-    if (rc) return rc;
-    if (counters) {
-        unsigned long long hc[8];
-        memcpy(hc, b->h_status + 2, sizeof hc);
-        counters[0] += (uint64_t)launches * (uint64_t)steps_per_launch * (uint64_t)b->N;
-        counters[1] += hc[4] - hc[0];       // per-game words are uint32 and wrap; a single call stays far below 2^32 per game
-        counters[2] += hc[5] - hc[1];
-        counters[3] += hc[6] - hc[2];
-    }
+    if ((rc = finish_call(b))) return rc;
     if (elapsed_ms) HIP_TRY(hipEventElapsedTime(elapsed_ms, b->ev0, b->ev1));
+    return TETRIS_OK;
+}
+
+int tetris_rollout_random(tetris_batch* b, int launches, int steps_per_launch, uint32_t policy_seed, uint64_t first_step,
+                          int ms, uint64_t counters[4], float* elapsed_ms) {
+    uint64_t before[4] = {0, 0, 0, 0}, after[4] = {0, 0, 0, 0};
+    int rc;
+    if (counters && (rc = tetris_rollout_totals(b, before))) return rc;
+    if ((rc = tetris_rollout_launch(b, launches, steps_per_launch, policy_seed, first_step, ms, elapsed_ms))) return rc;
+    if (counters) {
+        if ((rc = tetris_rollout_totals(b, after))) return rc;
+        // per-game words are uint32 and wrap; a single call stays far below 2^32 per game
+        for (int k = 0; k < 4; k++) counters[k] += after[k] - before[k];
+    }
     return TETRIS_OK;
 }
 

@@ -13,13 +13,15 @@ namespace te {
 struct KArgs {
     uint32_t* state;
     uint32_t* gstate;
-    uint32_t* status;
+    uint32_t* status;         // the batch's flag words (te::Flag; pinned host memory in the product)
     const uint8_t* table;     // [(chunk * 65536 + seed16) * 624 + r]
     const uint64_t* start;    // [65536] per-seed start entries
     const double* combo_pow;
     uint32_t n_draws, margin;
     int H;
     int n_games;              // N (stride of the SoA arrays)
+    int n_players;            // P
+    int nw;                   // words per player-board (NWORDS, or NWORDS_TINT with colour planes)
     int n;                    // lanes with work
     const int32_t* idx;       // NULL: identity
     const uint8_t* keys;      // [max_keys][P][n]
@@ -29,6 +31,7 @@ struct KArgs {
     const uint8_t* trans;     // [n]
     const uint8_t* player;    // [n] or NULL
     const int16_t* seeds;     // [n] or NULL
+    const uint8_t* mask;      // [n] or NULL: lanes with mask[i] == 0 do nothing (device-side reset of finished games)
     int ms;
     uint8_t* done;            // [n]
     uint8_t* lines;           // [P][n]
@@ -43,7 +46,9 @@ struct KArgs {
     uint32_t* xout;           // split mode: this stage's word per board [n]
 };
 
-enum Mode { M_INIT, M_RESET, M_MAKE, M_FINISH, M_STEP_KEYS, M_STEP_RT, M_ROLLOUT, M_SPLIT_INIT, M_SPLIT_RESET };
+enum Mode { M_INIT, M_RESET, M_MAKE, M_FINISH, M_STEP_KEYS, M_STEP_RT, M_ROLLOUT, M_SPLIT_INIT, M_SPLIT_RESET,
+            M_STEP_RT_AUTO,      // M_STEP_RT + device-side auto-reset of finished games (seed schedule of the rollout)
+            M_RESET_SCHED };     // reset with the next seed of the schedule (no seed array)
 
 struct LaneCounters { unsigned long long steps, episodes, lines, sent; };   // used by the CPU test harness only
 
@@ -54,9 +59,26 @@ TE_HD size_t safe_slot(const int32_t* idx, int i, int n_games) {
     const uint32_t v = (uint32_t)idx[i];
     return (size_t)(v < (uint32_t)n_games ? v : (uint32_t)n_games - 1u);
 }
-TE_HD int safe_player(const uint8_t* player, int i, int P) {
-    const int v = player ? (int)player[i] : 0;
-    return v < P ? v : P - 1;
+TE_HD int safe_player_value(int v, int P) { return v < P ? v : P - 1; }
+TE_HD int safe_player(const uint8_t* player, int i, int P) { return safe_player_value(player ? (int)player[i] : 0, P); }
+
+// a lane has work: inside the launch and, for masked launches, selected by the device-side mask
+TE_HD bool lane_active(const KArgs& a, int i) { return i < a.n && (!a.mask || a.mask[i] != 0); }
+
+TE_HD Geo geo_of(const KArgs& a, uint32_t* state = nullptr) {
+    Geo g = {state ? state : a.state, a.gstate, (size_t)a.n_games, a.n_players, a.nw};
+    return g;
+}
+
+// A lane's collected status bits -> the batch's flag words (plain stores; rare).  F_EXTEND carries the table size the
+// kernel worked with, so the host can tell a fresh request from one that an extension has already answered.
+TE_HD void report_status(const KArgs& a, uint32_t st) {
+    if (!st) return;
+    volatile uint32_t* f = a.status;
+    if (st & ST_NEED_EXTEND) f[F_EXTEND] = a.n_draws;
+    if (st & ST_STREAM_EXHAUSTED) f[F_EXHAUSTED] = 1u;
+    if (st & ST_FIFO_OVERFLOW) f[F_FIFO] = 1u;
+    if (st & ST_BAD_ARGUMENT) f[F_BADARG] = 1u;
 }
 
 TE_HD Ctx make_ctx(const KArgs& a, const uint32_t* shapes, bool tint = false, bool queue = true) {
@@ -122,17 +144,17 @@ TE_HD void policy_draw(const KArgs& a, uint32_t slot, unsigned long long step, u
 template <int P, int MODE, bool TINT = false>
 TE_HD void game_load(const KArgs& a, int i, Game<P>& g) {
     const size_t slot = a.idx ? (size_t)a.idx[i] : (size_t)i;
-    if (MODE != M_INIT && MODE != M_SPLIT_INIT) load_game<P>(a.state, a.gstate, (size_t)a.n_games, slot, g, TINT, P > 1 || MODE == M_SPLIT_RESET);   // split batches: 1-player layout WITH a queue
+    if (MODE != M_INIT && MODE != M_SPLIT_INIT)
+        load_game<P>(geo_of(a), slot, g, TINT, P > 1 || MODE == M_SPLIT_RESET, MODE == M_ROLLOUT);   // split batches: 1-player layout WITH a queue
     // the first step's draw depends on kernel arguments only: its 40 dependent multiplies run while the state loads are in flight
     if (MODE == M_ROLLOUT) policy_draw(a, (uint32_t)slot, a.first_step, g.draw0, g.draw1);
     // (r, t) actions: the three action bytes are requested together with the state, not after it has arrived
-    if (MODE == M_STEP_RT) { g.draw0 = a.rot[i]; g.draw1 = (uint32_t)a.trans[i] | ((a.player ? (uint32_t)a.player[i] : 0u) << 8); }
+    if (MODE == M_STEP_RT || MODE == M_STEP_RT_AUTO) { g.draw0 = a.rot[i]; g.draw1 = (uint32_t)a.trans[i] | ((a.player ? (uint32_t)a.player[i] : 0u) << 8); }
 }
 
 // Phase 2: step and store.
 template <int P, int MODE, bool TINT = false>
 TE_HD void game_run(const KArgs& a, int i, const uint32_t* shapes, Game<P>& g, LaneCounters& cnt) {
-    const size_t N = (size_t)a.n_games;
     const size_t slot = a.idx ? (size_t)a.idx[i] : (size_t)i;
     Ctx cx = make_ctx(a, shapes, TINT, P > 1 || MODE == M_SPLIT_INIT || MODE == M_SPLIT_RESET);
     if (MODE == M_INIT) init_game<P>(cx, g, (uint32_t)(a.seeds ? (uint16_t)a.seeds[i] : 0));
@@ -143,6 +165,9 @@ TE_HD void game_run(const KArgs& a, int i, const uint32_t* shapes, Game<P>& g, L
         if (P == 1) reset_split(cx, *reinterpret_cast<Game<1>*>(&g), (uint32_t)(a.seeds ? (uint16_t)a.seeds[i] : 0));
     } else if (MODE == M_RESET) {
         reset_game<P>(cx, g, (uint32_t)(a.seeds ? (uint16_t)a.seeds[i] : 0));
+    } else if (MODE == M_RESET_SCHED) {     // worker.py:157-166 with the SURVEY §8(d) seed schedule, decided on the device
+        g.episode++;
+        reset_game<P>(cx, g, episode_seed(a.game_offset + (uint32_t)slot, g.episode));
     } else if (MODE == M_MAKE) {
         make_keys<P>(cx, a, i, g);
     } else if (MODE == M_FINISH) {
@@ -156,12 +181,19 @@ TE_HD void game_run(const KArgs& a, int i, const uint32_t* shapes, Game<P>& g, L
         make_keys<P>(cx, a, i, g);
         int done = finish_game<P>(cx, g, a.ms);
         write_outputs<P>(a, i, g, done);
-    } else if (MODE == M_STEP_RT) {
+    } else if (MODE == M_STEP_RT || MODE == M_STEP_RT_AUTO) {
         TE_UNROLL
         for (int p = 0; p < P; p++) prefetch_next(cx, g.pl[p], g.seed16, g.status);
+        ResetPrefetch rpf;
+        rpf.ok = 0; rpf.seed16 = 0; rpf.word = 0;
+        if (MODE == M_STEP_RT_AUTO) prefetch_reset(cx, episode_seed(a.game_offset + (uint32_t)slot, g.episode + 1), rpf);
         make_rt<P>(cx, g, (int)(g.draw1 >> 8), (int)(g.draw0 & 3u), (int)(g.draw1 & 0xFFu));
         int done = finish_game<P>(cx, g, a.ms);
-        write_outputs<P>(a, i, g, done);
+        write_outputs<P>(a, i, g, done);                 // done / lines / dead as they stand BEFORE the reset
+        if (MODE == M_STEP_RT_AUTO && done) {            // worker.py:157-166 reset_envs, without the host round trip
+            g.episode++;
+            reset_game<P>(cx, g, episode_seed(a.game_offset + (uint32_t)slot, g.episode), &rpf);
+        }
     } else if (MODE == M_ROLLOUT) {
         // SURVEY.md §8(d) synthetic workload: worker.py:91-118 with a counter-based random policy
         for (int s = 0; s < a.steps; s++) {
@@ -181,14 +213,15 @@ TE_HD void game_run(const KArgs& a, int i, const uint32_t* shapes, Game<P>& g, L
             int done = finish_game<P>(cx, g, a.ms);
             TE_STAMP(7);
             cnt.steps++;
+            g.steps++;
             uint32_t sent_after = 0;
             TE_UNROLL
             for (int p = 0; p < P; p++) {
                 sent_after += g.pl[p].lines_sent;
-                if (!g.pl[p].dead) { cnt.lines += (unsigned)g.pl[p].reward; g.roll_lines += (unsigned)g.pl[p].reward; }
+                if (!g.pl[p].dead) { cnt.lines += (unsigned)g.pl[p].reward; g.add_lines += (unsigned)g.pl[p].reward; }
             }
             cnt.sent += (sent_after - sent_before) & 0xFFFFu;
-            g.roll_sent += (sent_after - sent_before) & 0xFFFFu;
+            g.add_sent += (sent_after - sent_before) & 0xFFFFu;
 #if defined(TE_ABLATE) && (TE_ABLATE & 16)
             done = 0;                                // diagnostic build: no auto-reset
 #endif
@@ -201,29 +234,24 @@ TE_HD void game_run(const KArgs& a, int i, const uint32_t* shapes, Game<P>& g, L
             TE_STAMP(8);
         }
     }
-    store_game<P>(a.state, a.gstate, N, slot, g, TINT, P > 1 || MODE == M_SPLIT_INIT || MODE == M_SPLIT_RESET);   // 1-player: FIFO words stay as zeroed at creation
-    if (g.status) {
-#if defined(__HIP_DEVICE_COMPILE__)
-        atomicOr(a.status, g.status);
-#else
-        *a.status |= g.status;
-#endif
-    }
+    store_game<P>(geo_of(a), slot, g, TINT, P > 1 || MODE == M_SPLIT_INIT || MODE == M_SPLIT_RESET,
+                  MODE == M_ROLLOUT || MODE == M_INIT || MODE == M_SPLIT_INIT);   // 1-player: FIFO words stay as zeroed at creation
+    report_status(a, g.status);
 }
 
 // Split mode (opponents on different GPUs, tetris_engine.h): one stage of a step for the side this batch holds.
 template <int STAGE, bool TINT = false>
 TE_HD void split_body(const KArgs& a, int i, const uint32_t* shapes) {
-    const size_t N = (size_t)a.n_games;
     Ctx cx = make_ctx(a, shapes, TINT);
     Game<1> g;
     const uint32_t my_a = STAGE > 0 ? a.xw[i] : 0u;
     const uint32_t opp_a = STAGE > 0 ? a.xw[(size_t)a.n + i] : 0u;
     // side 1 continues from its speculative post-settle state unless player 0 died in loop 1
-    const uint32_t meta = a.gstate[(size_t)G_META * N + i];
+    const uint32_t meta = word_at(game_ref(geo_of(a), (size_t)i), G_META);
     const int side = (int)((meta >> 21) & 1u);
     const bool from_shadow = STAGE == 1 && side == 1 && !(opp_a & XW_DIED);
-    load_game<1>(from_shadow ? a.shadow : a.state, a.gstate, N, (size_t)i, g, TINT);
+    const bool counting = STAGE == 2 && a.steps;         // built-in rollout: G_STEPS is kept by the last stage
+    load_game<1>(geo_of(a, from_shadow ? a.shadow : a.state), (size_t)i, g, TINT, true, counting);
     Player& q = g.pl[0];
     const uint32_t sent_before = q.lines_sent;
     if (STAGE == 0) {
@@ -236,12 +264,12 @@ TE_HD void split_body(const KArgs& a, int i, const uint32_t* shapes) {
         }
         prefetch_next(cx, q, g.seed16, g.status);
         if (!g.round_over && !q.dead && acting == side) play_rt(cx, q, r, t);
-        if (side == 1) store_game<1>(a.state, a.gstate, N, (size_t)i, g, TINT);        // post-make, pre-settle
+        if (side == 1) store_game<1>(geo_of(a), (size_t)i, g, TINT);        // post-make, pre-settle
         a.xout[i] = split_settle(cx, g);
         // rollout counter: side 1's loop-1 pass is speculative and the game words are not shadowed, so side 1 counts
         // these lines at stage 1, once it knows the pass is committed
-        if (side == 0) g.roll_sent += (q.lines_sent - sent_before) & 0xFFFFu;
-        store_game<1>(side == 1 ? a.shadow : a.state, a.gstate, N, (size_t)i, g, TINT);
+        if (side == 0) g.add_sent += (q.lines_sent - sent_before) & 0xFFFFu;
+        store_game<1>(geo_of(a, side == 1 ? a.shadow : a.state), (size_t)i, g, TINT);
     } else if (STAGE == 1) {
         uint32_t w;
         if (side == 0) {
@@ -253,12 +281,12 @@ TE_HD void split_body(const KArgs& a, int i, const uint32_t* shapes) {
             const int in1 = ((opp_a & XW_RAN) && !(opp_a & XW_DIED)) ? xw_sent(opp_a) : 0;
             if (!g.round_over && in1 > 0) q.incoming = q.incoming + (float)in1 / 1.0f;   // loop 1, PythonHandle.cpp:121
             const int in2 = (opp_b & XW_DIED) ? 0 : xw_sent(opp_b);                      // loop 2, :175
-            if (from_shadow && (my_a & XW_RAN) && !(my_a & XW_DIED)) g.roll_sent += (uint32_t)xw_sent(my_a);   // committed loop-1 lines
+            if (from_shadow && (my_a & XW_RAN) && !(my_a & XW_DIED)) g.add_sent += (uint32_t)xw_sent(my_a);   // committed loop-1 lines
             w = split_tick(cx, g, a.ms, in2);
         }
         a.xout[i] = w;
-        g.roll_sent += (q.lines_sent - sent_before) & 0xFFFFu;
-        store_game<1>(a.state, a.gstate, N, (size_t)i, g, TINT);
+        g.add_sent += (q.lines_sent - sent_before) & 0xFFFFu;
+        store_game<1>(geo_of(a), (size_t)i, g, TINT);
     } else {
         const uint32_t opp_b = a.xw[(size_t)(side == 0 ? 3 : 2) * a.n + i];
         const int in = (side == 0 && !(opp_b & XW_DIED)) ? xw_sent(opp_b) : 0;
@@ -267,18 +295,13 @@ TE_HD void split_body(const KArgs& a, int i, const uint32_t* shapes) {
         if (a.lines) a.lines[i] = (uint8_t)q.reward;
         if (a.dead) a.dead[i] = (uint8_t)q.dead;
         if (a.steps) {          // built-in rollout: counters and auto-reset, the same decision on both sides of the game
-            if (!q.dead) g.roll_lines += (unsigned)q.reward;
+            g.steps++;
+            if (!q.dead) g.add_lines += (unsigned)q.reward;
             if (done) { g.episode++; reset_split(cx, g, episode_seed(a.game_offset + (uint32_t)i, g.episode)); }
         }
-        store_game<1>(a.state, a.gstate, N, (size_t)i, g, TINT);
+        store_game<1>(geo_of(a), (size_t)i, g, TINT, true, counting);
     }
-    if (g.status) {
-#if defined(__HIP_DEVICE_COMPILE__)
-        atomicOr(a.status, g.status);
-#else
-        *a.status |= g.status;
-#endif
-    }
+    report_status(a, g.status);
 }
 
 template <int P, int MODE, bool TINT = false>
@@ -290,11 +313,11 @@ TE_HD void game_body(const KArgs& a, int i, const uint32_t* shapes, LaneCounters
 
 // State views / __getstate__ (PythonHandle.h:54-82,123-308) of one game -> P records
 template <int P, bool TINT = false>
-TE_HD void observe_body(const uint32_t* state, const uint32_t* gstate, int n_games, int i, const int32_t* idx, int H,
+TE_HD void observe_body(const Geo& geo, int i, const int32_t* idx, int H,
                         const uint32_t* shapes, tetris_record* rec, uint8_t* round_over, int8_t* last_winner) {
     size_t slot = idx ? (size_t)idx[i] : (size_t)i;
     Game<P> g;
-    load_game<P>(state, gstate, (size_t)n_games, slot, g, TINT);
+    load_game<P>(geo, slot, g, TINT);
     if (round_over) round_over[i] = (uint8_t)g.round_over;
     if (last_winner) last_winner[i] = (int8_t)g.last_winner;
     if (!rec) return;
@@ -347,16 +370,15 @@ TE_HD void observe_body(const uint32_t* state, const uint32_t* gstate, int n_gam
 
 // state_dict + unpacker for one player-board (state_processors.py:23-54, state_unpack.py:88-137):
 // `cells` receives H*10 bytes (field > 0, row-major), `vec` 12 bytes, returns the piece index
-TE_HD int observe_board(const uint32_t* state, int n_games, size_t slot, int P, int p, int H, uint8_t* cells, uint8_t* vec) {
-    const size_t ws = (size_t)P * n_games;
-    const uint32_t* s = state + (size_t)p * n_games + slot;
+TE_HD int observe_board(const Geo& geo, size_t slot, int p, int H, uint8_t* cells, uint8_t* vec) {
+    const Ref br = board_ref(geo, p, slot);
     uint32_t col[NCOL];
-    for (int c = 0; c < NCOL; c++) col[c] = s[(size_t)(W_COL0 + c) * ws];
+    for (int c = 0; c < NCOL; c++) col[c] = word_at(br, W_COL0 + c);
     for (int y = 0; y < H; y++)
         for (int c = 0; c < NCOL; c++) cells[y * NCOL + c] = (uint8_t)((col[c] >> y) & 1u);
-    const uint32_t w = s[(size_t)W_PIECE * ws];
-    const uint32_t m = s[(size_t)W_MISC * ws];
-    const uint32_t dc = s[(size_t)W_DROPCOMBO * ws];
+    const uint32_t w = word_at(br, W_PIECE);
+    const uint32_t m = word_at(br, W_MISC);
+    const uint32_t dc = word_at(br, W_DROPCOMBO);
     const int x = (int)((w >> 5) & 15) - 4, y = (w >> 9) & 31, next = (w >> 14) & 7;
     uint32_t t = ((dc >> 16) + 50u) & 0xFFFFu;            // uint16 array + 50 wraps like numpy (state_processors.py:38)
     if (t > 25000u) t = 25000u;
@@ -368,16 +390,15 @@ TE_HD int observe_board(const uint32_t* state, int n_games, size_t slot, int P, 
 // TestField.cpp:64-125 (drop placements): lane t = (game i, rotation r, column index xi)
 template <int P>
 // `after_row`: row of `after` ([row][10] words) this placement writes
-TE_HD void enumerate_body(const uint32_t* state, int n_games, size_t t, const int32_t* idx, const uint8_t* player, int H,
+TE_HD void enumerate_body(const Geo& geo, size_t t, const int32_t* idx, const uint8_t* player, int H,
                           const uint32_t* shapes, uint8_t* valid, int8_t* land_y, uint8_t* cleared, uint32_t* after, size_t after_row) {
     const int i = (int)(t / 40), j = (int)(t % 40), r = j / 10, xi = j % 10;
-    const size_t slot = safe_slot(idx, i, n_games);
+    const size_t slot = safe_slot(idx, i, (int)geo.n_games);
     const int p = safe_player(player, i, P);
-    const size_t ws = (size_t)P * n_games;
-    const uint32_t* s = state + (size_t)p * n_games + slot;
+    const Ref br = board_ref(geo, p, slot);
     Player q;
-    for (int c = 0; c < NCOL; c++) q.col[c] = s[(size_t)(W_COL0 + c) * ws];
-    const uint32_t w = s[(size_t)W_PIECE * ws];
+    for (int c = 0; c < NCOL; c++) q.col[c] = word_at(br, W_COL0 + c);
+    const uint32_t w = word_at(br, W_PIECE);
     const int kind = w & 7, cur_rot = (w >> 3) & 3;
     Ctx cx;
     cx.shapes = shapes; cx.H = H; cx.floor_bits = ~0u << H; cx.tint = false; cx.queue = true;
@@ -403,17 +424,16 @@ TE_HD void enumerate_body(const uint32_t* state, int n_games, size_t t, const in
 // PythonHandle.cpp:190 get_actions -> TestField.cpp:64-111 getMask(2): lane t = (game i, rotation r, column xi);
 // slab of lane t: count[t], lens[t][max_lists], keys[t][max_lists][max_keys]
 template <int P>
-TE_HD void actions_body(const uint32_t* state, int n_games, size_t t, const int32_t* idx, const uint8_t* player, int H,
+TE_HD void actions_body(const Geo& geo, size_t t, const int32_t* idx, const uint8_t* player, int H,
                         const uint32_t* shapes, uint8_t* count, uint8_t* lens, uint8_t* keys, int max_lists, int max_keys,
                         uint32_t* status) {
     const int i = (int)(t / 40), j = (int)(t % 40), r = j / 10, xi = j % 10;
-    const size_t slot = safe_slot(idx, i, n_games);
+    const size_t slot = safe_slot(idx, i, (int)geo.n_games);
     const int p = safe_player(player, i, P);
-    const size_t ws = (size_t)P * n_games;
-    const uint32_t* s = state + (size_t)p * n_games + slot;
+    const Ref br = board_ref(geo, p, slot);
     Probe pr;
-    for (int c = 0; c < NCOL; c++) pr.q.col[c] = s[(size_t)(W_COL0 + c) * ws];
-    const uint32_t w = s[(size_t)W_PIECE * ws];
+    for (int c = 0; c < NCOL; c++) pr.q.col[c] = word_at(br, W_COL0 + c);
+    const uint32_t w = word_at(br, W_PIECE);
     const int kind = w & 7, cur_rot = (w >> 3) & 3;
     Ctx cx;
     cx.shapes = shapes; cx.H = H; cx.floor_bits = ~0u << H; cx.tint = false; cx.queue = true;
@@ -425,43 +445,38 @@ TE_HD void actions_body(const uint32_t* state, int n_games, size_t t, const int3
     pr.max_lists = max_lists; pr.max_keys = max_keys; pr.n_lists = 0; pr.overflow = 0;
     if (kind <= 6 && r < n_rot && pr.q.x <= NCOL - 2 && probe_fits(cx, pr)) probe_column(cx, pr);
     count[t] = (uint8_t)imin(pr.n_lists, 255);
-    if (pr.overflow || pr.n_lists > max_lists) {
-#if defined(__HIP_DEVICE_COMPILE__)
-        atomicOr(status, (uint32_t)ST_BAD_ARGUMENT);
-#else
-        *status |= ST_BAD_ARGUMENT;
-#endif
-    }
+    if (pr.overflow || pr.n_lists > max_lists) ((volatile uint32_t*)status)[F_BADARG] = 1u;
 }
 
-// per-game cumulative rollout counters of one game -> {episodes, lines, sent}
-TE_HD void totals_of_game(const uint32_t* gstate, int n_games, int i, unsigned long long out[3]) {
-    out[0] = gstate[(size_t)G_EPISODE * n_games + i];
-    out[1] = gstate[(size_t)G_LINES * n_games + i];
-    out[2] = gstate[(size_t)G_SENT * n_games + i];
+// per-game cumulative rollout counters of one game -> {env-steps, episodes, lines, sent}
+TE_HD void totals_of_game(const Geo& geo, int i, unsigned long long out[4]) {
+    const Ref gr = game_ref(geo, (size_t)i);
+    out[0] = word_at(gr, G_STEPS);
+    out[1] = word_at(gr, G_EPISODE);
+    out[2] = word_at(gr, G_LINES);
+    out[3] = word_at(gr, G_SENT);
 }
 
-// PythonHandle.cpp:36-42 copy / set: raw words, blob[i][NGWORDS + P*NWORDS]; t = lane = (game i, word)
-TE_HD void snapshot_body(uint32_t* state, uint32_t* gstate, int n_games, size_t t, const int32_t* idx, int P, uint32_t* blob,
-                         int restore, int nw = NWORDS) {
-    const int words = NGWORDS + P * nw;
+// PythonHandle.cpp:36-42 copy / set: raw words, blob[i][NGWORDS + P*nw]; t = lane = (game i, word)
+TE_HD void snapshot_body(const Geo& geo, size_t t, const int32_t* idx, uint32_t* blob, int restore) {
+    const int words = NGWORDS + geo.P * geo.nw;
     int i = (int)(t / (size_t)words), w = (int)(t % (size_t)words);
     size_t slot = idx ? (size_t)idx[i] : (size_t)i;
     uint32_t* cell;
-    if (w < NGWORDS) cell = &gstate[(size_t)w * n_games + slot];
+    if (w < NGWORDS) cell = &word_at(game_ref(geo, slot), w);
     else {
-        int pw = w - NGWORDS, p = pw / nw, ww = pw % nw;
-        cell = &state[((size_t)ww * P + p) * n_games + slot];
+        int pw = w - NGWORDS, p = pw / geo.nw, ww = pw % geo.nw;
+        cell = &word_at(board_ref(geo, p, slot), ww);
     }
     if (restore) *cell = blob[t];
     else blob[t] = *cell;
 }
 
 // data_types/state.py:11,16: Python writes State.dead
-TE_HD void set_dead_body(uint32_t* state, int n_games, int t, const int32_t* idx, int P, const uint8_t* dead) {
-    int i = t / P, p = t % P;
+TE_HD void set_dead_body(const Geo& geo, int t, const int32_t* idx, const uint8_t* dead) {
+    int i = t / geo.P, p = t % geo.P;
     size_t slot = idx ? (size_t)idx[i] : (size_t)i;
-    uint32_t* cell = &state[((size_t)W_PIECE * P + p) * n_games + slot];
+    uint32_t* cell = &word_at(board_ref(geo, p, slot), W_PIECE);
     *cell = (*cell & ~(1u << 17)) | ((uint32_t)(dead[t] ? 1u : 0u) << 17);
 }
 

@@ -53,18 +53,61 @@ enum Word : int {
 
 enum GameWord : int {
     G_META = 0,     // seed16[0:16) round_over[16] last_winner+1[17:21) | split mode: side[21] opp_dead[22] split[23]
-    G_EPISODE = 1,  // episodes finished by the built-in rollout (SURVEY.md §8d seed schedule)
-    G_LINES = 2,    // lines cleared during built-in rollouts (cumulative; summed by k_totals)
-    G_SENT = 3,     // garbage lines sent during built-in rollouts (cumulative)
-    NGWORDS = 4
+    G_EPISODE = 1,  // episodes finished by the built-in rollout / device-side auto-reset (SURVEY.md §8d seed schedule)
+    G_STEPS = 2,    // env-steps executed on this game by the built-in rollout (cumulative; summed by k_totals)
+    G_LINES = 3,    // lines cleared during built-in rollouts (cumulative; touched only when a line was cleared)
+    G_SENT = 4,     // garbage lines sent during built-in rollouts (cumulative; touched only when lines were sent)
+    NGWORDS = 5,
+    NGWORDS_HOT = 3 // read and written by every rollout step
 };
 
-// sticky status bits written by kernels into the batch's device status word
+// status bits a lane collects while stepping its game; reported through the batch's flag words (below)
 enum Status : uint32_t {
     ST_NEED_EXTEND = 1u,        // some board is within `margin` draws of the end of the RNG tables
     ST_STREAM_EXHAUSTED = 2u,   // a draw index ran past the tables (results invalid)
     ST_FIFO_OVERFLOW = 4u,      // more than FIFO_CAP pending garbage packets (results invalid)
     ST_BAD_ARGUMENT = 8u,
 };
+
+// Flag words of a batch: pinned host memory that the GPU writes with plain stores (rare) and the host reads without
+// enqueuing anything, so the asynchronous entry points (tetris_step_rt_dev, the rollout launches) can service
+// "extend the RNG tables" requests without a copy or a stream drain per launch.
+enum Flag : int {
+    F_EXTEND = 0,      // n_draws as seen by a kernel in which a board came within `margin` of the table end (0 = no request)
+    F_EXHAUSTED = 1,   // != 0: a draw index ran past the tables
+    F_FIFO = 2,        // != 0: a garbage queue overflowed
+    F_BADARG = 3,      // != 0: an output capacity was exceeded (get_actions)
+    NFLAGS = 8
+};
+
+// ---------------------------------------------------------------- addressing
+// Every access to a batch's state goes through these two functions, so the memory layout is decided here and
+// nowhere else.  A `Ref` names one player-board (or one game's game words): word w lives `o` bytes past s[w * ws].
+// `s` and `ws` are uniform across a wave whose lanes hold consecutive games; `o` is the lane's 32-bit byte offset.
+struct Ref { uint32_t* s; uint32_t o; size_t ws; };
+
+// Geometry of one batch: N games, P players, nw words per player-board; `state` and `gstate` are its allocations.
+struct Geo { uint32_t* state; uint32_t* gstate; size_t n_games; int P; int nw; };
+
+#if defined(__HIPCC__)
+#define TE_LAYOUT_HD __host__ __device__ __forceinline__
+#else
+#define TE_LAYOUT_HD static inline
+#endif
+
+// layout "rows": state[(w * P + p) * N + slot], gstate[gw * N + slot]
+TE_LAYOUT_HD Ref board_ref(const Geo& g, int p, size_t slot) {
+    Ref r = {g.state + (size_t)p * g.n_games, (uint32_t)slot * 4u, (size_t)g.P * g.n_games};
+    return r;
+}
+TE_LAYOUT_HD Ref game_ref(const Geo& g, size_t slot) {
+    Ref r = {g.gstate, (uint32_t)slot * 4u, g.n_games};
+    return r;
+}
+// plain (cached) access to one word, for the kernels that touch a few words of many games
+TE_LAYOUT_HD uint32_t& word_at(const Ref& r, int w) { return *(uint32_t*)((char*)(r.s + (size_t)w * r.ws) + r.o); }
+// allocation sizes in words
+TE_LAYOUT_HD size_t state_words(size_t n_games, int P, int nw) { return (size_t)nw * P * n_games; }
+TE_LAYOUT_HD size_t gstate_words(size_t n_games) { return (size_t)NGWORDS * n_games; }
 
 }  // namespace te

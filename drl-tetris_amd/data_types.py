@@ -186,8 +186,10 @@ class backend_snapshot:
 
     def sync_dead_to_blob(self):
         """Python may write `states[p].dead[0]` (state.py:11,16); carry it into the restore words."""
+        # words per player-board come from the blob itself: 39, or 69 for batches with colour planes (tetris_layout.h)
+        nw = (len(self.blob) - layout.NGWORDS) // len(self.states)
         for p, s in enumerate(self.states):
-            w = layout.NGWORDS + p * layout.NWORDS + layout.W_PIECE
+            w = layout.NGWORDS + p * nw + layout.W_PIECE
             self.blob[w] = (self.blob[w] & ~np.uint32(1 << 17)) | (np.uint32(1 << 17) if s.dead[0] else np.uint32(0))
 
 

@@ -45,14 +45,18 @@ class ShardedRollout:
 
     def run(self, launches, steps_per_launch=1, timed=True):
         """Advances every game of every rank by launches * steps_per_launch env-steps.
-        -> dict(counters = sum over ranks [env_steps, episodes, lines, sent], wall_s and event_ms = max over ranks)."""
+        -> dict(counters = sum over ranks [env_steps, episodes, lines, sent], wall_s and event_ms = max over ranks).
+        Only the step-kernel launches lie inside the clocked region (barrier + synchronize on both sides of it): the
+        counters are per-game words kept by the kernels themselves (env-steps are counted on the device) and are summed by a
+        separate kernel before and after, outside the region."""
+        before = self.batch.rollout_totals()
         self._sync()
         t0 = time.perf_counter()
-        counters, ev_ms = self.batch.rollout_random(launches, steps_per_launch, first_step=self.next_step)
+        ev_ms = self.batch.rollout_launch(launches, steps_per_launch, first_step=self.next_step)
         self._sync()
         wall = time.perf_counter() - t0
+        counters = (self.batch.rollout_totals() - before).astype(np.int64)
         self.next_step += launches * steps_per_launch
-        counters = counters.astype(np.int64)
         if self.dist is not None:
             import torch
             dev = "cuda" if torch.cuda.is_available() and self.dist.get_backend() == "nccl" else "cpu"

@@ -110,6 +110,20 @@ int tetris_step_rt(tetris_batch *b, const uint8_t *rot, const uint8_t *trans, co
 int tetris_step_rt_dev(tetris_batch *b, const uint8_t *d_rot, const uint8_t *d_trans,
                        const uint8_t *d_player, int ms, uint8_t *d_done, uint8_t *d_lines,
                        uint8_t *d_dead);
+/* same with flags.  TETRIS_STEP_AUTO_RESET: a game whose round ended in this step is reset inside the same launch —
+ * the `env.reset(env=[done idxs])` of the worker loop (drl_tetris/worker.py:157-166 -> PythonHandle.cpp:49-71) without
+ * a host round trip.  The seed is the next one of the built-in schedule, seed16 = (12345 + 7919 game + 104729 episode)
+ * mod 65536 with game = global game id (tetris_set_game_offset) and episode = the game's count of resets so far;
+ * d_done / d_lines / d_dead report the step as it ended, BEFORE the reset.
+ * The asynchronous entry points never drain the stream: requests to extend the RNG tables reach the host through
+ * flag words in pinned memory, and the host lets at most 65 launches run ahead of what it has seen of them.        */
+#define TETRIS_STEP_AUTO_RESET 1
+int tetris_step_rt_dev_ex(tetris_batch *b, const uint8_t *d_rot, const uint8_t *d_trans,
+                          const uint8_t *d_player, int ms, uint8_t *d_done, uint8_t *d_lines,
+                          uint8_t *d_dead, int flags);
+/* replaces: reset() of the games selected by a DEVICE-side mask (d_mask[N], non-zero = reset; NULL = all games),
+ * asynchronous.  d_seeds[N] int16 (device) or NULL = next seed of the built-in schedule (see above).              */
+int tetris_reset_dev(tetris_batch *b, const uint8_t *d_mask, const int16_t *d_seeds);
 
 /* replaces: reading PythonHandle.states[p].* / __getstate__() (PythonHandle.h:54-82,123-308).
  * records[n][P]; round_over[n]; last_winner[n] (PythonHandle.last_winner); NULLs allowed.       */
@@ -169,6 +183,11 @@ int tetris_get_actions(tetris_batch *b, const int32_t *idx, int n, const uint8_t
  * = HIP-event time from before the first to after the last launch on the batch's stream.        */
 int tetris_rollout_random(tetris_batch *b, int launches, int steps_per_launch, uint32_t policy_seed,
                           uint64_t first_step, int ms, uint64_t counters[4], float *elapsed_ms);
+/* The launches of tetris_rollout_random alone: nothing but the `launches` step kernels lies between the two HIP events
+ * and between call and return (plus one final stream synchronisation) — the region bench.py times.  Counters are read
+ * with tetris_rollout_totals before and after, outside that region.                                                */
+int tetris_rollout_launch(tetris_batch *b, int launches, int steps_per_launch, uint32_t policy_seed,
+                          uint64_t first_step, int ms, float *elapsed_ms);
 
 /* Global id of this batch's game 0 (default 0): the built-in rollout keys its policy and its
  * reset-seed schedule by global game id, so that N batches on N GPUs simulate N*n_games distinct
@@ -198,9 +217,10 @@ int tetris_split_stage_dev(tetris_batch *b, int stage, const uint8_t *d_rot, con
  * needed inside a rollout.  d_words / d_out as for tetris_split_stage_dev.                                          */
 int tetris_split_rollout_stage_dev(tetris_batch *b, int stage, uint32_t policy_seed, uint64_t step, int ms,
                                    const uint32_t *d_words, uint32_t *d_out);
-/* cumulative counters of the built-in rollouts of this batch: totals[3] = {episodes, lines_cleared, garbage_sent}
- * (sums of the per-game words; synchronous).                                                                       */
-int tetris_rollout_totals(tetris_batch *b, uint64_t totals[3]);
+/* cumulative counters of the built-in rollouts of this batch: totals[4] = {env_steps, episodes, lines_cleared,
+ * garbage_sent}, each the sum over the games of a per-game word the step kernels keep (env_steps is COUNTED on the
+ * device, one increment per game and step, not computed from the launch arguments); synchronous.                  */
+int tetris_rollout_totals(tetris_batch *b, uint64_t totals[4]);
 
 /* Run the batch on a caller-owned HIP stream (e.g. torch's current stream) so that its kernels are ordered with the
  * caller's copies and collectives without host synchronisation.  external != 0: use `hip_stream` as given — NULL is

@@ -71,7 +71,7 @@ static Tables* tables_for(const uint8_t map[7]) {
 struct tetris_batch {
     int N, P, H;
     std::vector<uint32_t> state, gstate;
-    uint32_t status = 0;
+    uint32_t flags[NFLAGS] = {0};
     uint32_t margin = 64;
     uint32_t game_offset = 0;
     int split = 0, side = 0;
@@ -83,11 +83,15 @@ struct tetris_batch {
 static KArgs base_args(tetris_batch* b, int n, const int32_t* idx) {
     KArgs a;
     memset(&a, 0, sizeof a);
-    a.state = b->state.data(); a.gstate = b->gstate.data(); a.status = &b->status;
+    a.state = b->state.data(); a.gstate = b->gstate.data(); a.status = b->flags;
     a.table = b->tab->table.data(); a.start = b->tab->start.data(); a.combo_pow = b->tab->powtab;
     a.n_draws = (uint32_t)b->tab->n_chunks * CHUNK; a.margin = b->margin;
-    a.H = b->H; a.n_games = b->N; a.n = n; a.idx = idx; a.game_offset = b->game_offset;
+    a.H = b->H; a.n_games = b->N; a.n_players = b->P; a.nw = b->nw; a.n = n; a.idx = idx; a.game_offset = b->game_offset;
     return a;
+}
+static Geo geo_of_batch(tetris_batch* b) {
+    Geo g = {b->state.data(), b->gstate.data(), (size_t)b->N, b->P, b->nw};
+    return g;
 }
 
 template <int MODE>
@@ -95,6 +99,7 @@ static void run(tetris_batch* b, const KArgs& a, LaneCounters* total = nullptr) 
     LaneCounters sum = {0, 0, 0, 0};
     for (int i = 0; i < a.n; i++) {
         LaneCounters c = {0, 0, 0, 0};
+        if (!lane_active(a, i)) continue;
         if (b->P == 1 && !b->tint) game_body<1, MODE, false>(a, i, SHAPES.s, c);
         else if (b->P == 1) game_body<1, MODE, true>(a, i, SHAPES.s, c);
         else if (!b->tint) game_body<2, MODE, false>(a, i, SHAPES.s, c);
@@ -105,14 +110,16 @@ static void run(tetris_batch* b, const KArgs& a, LaneCounters* total = nullptr) 
 }
 
 static int finish_call(tetris_batch* b) {
-    uint32_t st = b->status;
-    if (st & ST_STREAM_EXHAUSTED) return fail(TETRIS_E_STREAM, "an episode ran past the RNG tables");
-    if (st & ST_FIFO_OVERFLOW) return fail(TETRIS_E_FIFO, "garbage FIFO overflow");
-    if (st & ST_NEED_EXTEND) {
-        if (b->tab->n_chunks >= MAX_CHUNKS) return fail(TETRIS_E_STREAM, "MAX_CHUNKS reached");
-        b->tab->extend();
-        b->status = 0;
+    if (b->flags[F_EXHAUSTED]) return fail(TETRIS_E_STREAM, "an episode ran past the RNG tables");
+    if (b->flags[F_FIFO]) return fail(TETRIS_E_FIFO, "garbage FIFO overflow");
+    if (b->flags[F_EXTEND]) {
+        if (b->flags[F_EXTEND] >= (uint32_t)b->tab->n_chunks * CHUNK) {
+            if (b->tab->n_chunks >= MAX_CHUNKS) return fail(TETRIS_E_STREAM, "MAX_CHUNKS reached");
+            b->tab->extend();
+        }
+        b->flags[F_EXTEND] = 0;
     }
+    if (b->flags[F_BADARG]) { b->flags[F_BADARG] = 0; return fail(TETRIS_E_ARG, "output capacity exceeded"); }
     return TETRIS_OK;
 }
 
@@ -171,11 +178,11 @@ static int create_impl(tetris_batch** out, int n_games, int n_players, int heigh
     tetris_batch* b = new tetris_batch();
     b->N = n_games; b->P = n_players; b->H = height;
     b->tint = (flags & TETRIS_FLAG_COLOURS) ? 1 : 0; b->nw = b->tint ? NWORDS_TINT : NWORDS;
-    b->state.assign((size_t)b->nw * n_players * n_games, 0);
-    b->gstate.assign((size_t)NGWORDS * n_games, 0);
+    b->state.assign(state_words((size_t)n_games, n_players, b->nw), 0);
+    b->gstate.assign(gstate_words((size_t)n_games), 0);
     b->tab = tables_for(piece_map);
     b->split = split; b->side = side;
-    if (split && side == 1) b->shadow.assign((size_t)b->nw * n_players * n_games, 0);
+    if (split && side == 1) b->shadow.assign(state_words((size_t)n_games, n_players, b->nw), 0);
     KArgs a = base_args(b, n_games, nullptr);
     a.seeds = seeds; a.steps = side;
     if (split) run<M_SPLIT_INIT>(b, a); else run<M_INIT>(b, a);
@@ -226,12 +233,12 @@ int tetris_split_rollout_stage_dev(tetris_batch* b, int stage, uint32_t policy_s
     }
     return TETRIS_OK;
 }
-int tetris_rollout_totals(tetris_batch* b, uint64_t totals[3]) {
-    totals[0] = totals[1] = totals[2] = 0;
+int tetris_rollout_totals(tetris_batch* b, uint64_t totals[4]) {
+    totals[0] = totals[1] = totals[2] = totals[3] = 0;
     for (int i = 0; i < b->N; i++) {
-        unsigned long long t[3];
-        totals_of_game(b->gstate.data(), b->N, i, t);
-        totals[0] += t[0]; totals[1] += t[1]; totals[2] += t[2];
+        unsigned long long t[4];
+        totals_of_game(geo_of_batch(b), i, t);
+        for (int k = 0; k < 4; k++) totals[k] += t[k];
     }
     return TETRIS_OK;
 }
@@ -290,11 +297,22 @@ int tetris_step_rt(tetris_batch* b, const uint8_t* rot, const uint8_t* trans, co
     return finish_call(b);
 }
 
-int tetris_step_rt_dev(tetris_batch* b, const uint8_t* rot, const uint8_t* trans, const uint8_t* player, int ms, uint8_t* done,
-                       uint8_t* lines, uint8_t* dead) {
+int tetris_step_rt_dev_ex(tetris_batch* b, const uint8_t* rot, const uint8_t* trans, const uint8_t* player, int ms, uint8_t* done,
+                          uint8_t* lines, uint8_t* dead, int flags) {
+    if (flags & ~TETRIS_STEP_AUTO_RESET) return fail(TETRIS_E_ARG, "unknown flag");
+    int rc = finish_call(b); if (rc) return rc;          // (the product polls its flag words here instead)
     KArgs a = base_args(b, b->N, nullptr); a.ms = ms; a.rot = rot; a.trans = trans; a.player = player;
     a.done = done; a.lines = lines; a.dead = dead;
-    run<M_STEP_RT>(b, a);
+    if (flags & TETRIS_STEP_AUTO_RESET) run<M_STEP_RT_AUTO>(b, a); else run<M_STEP_RT>(b, a);
+    return TETRIS_OK;
+}
+int tetris_step_rt_dev(tetris_batch* b, const uint8_t* rot, const uint8_t* trans, const uint8_t* player, int ms, uint8_t* done,
+                       uint8_t* lines, uint8_t* dead) { return tetris_step_rt_dev_ex(b, rot, trans, player, ms, done, lines, dead, 0); }
+int tetris_reset_dev(tetris_batch* b, const uint8_t* mask, const int16_t* seeds) {
+    if (b->split) return fail(TETRIS_E_ARG, "tetris_reset_dev is not available on split batches");
+    int rc = finish_call(b); if (rc) return rc;
+    KArgs a = base_args(b, b->N, nullptr); a.mask = mask; a.seeds = seeds;
+    if (seeds) run<M_RESET>(b, a); else run<M_RESET_SCHED>(b, a);
     return TETRIS_OK;
 }
 
@@ -302,10 +320,11 @@ int tetris_observe_records(tetris_batch* b, const int32_t* idx, int n, tetris_re
                            int8_t* last_winner) {
     int rc = check_idx(b, idx, n); if (rc) return rc;
     for (int i = 0; i < n; i++) {
-        if (b->P == 1 && !b->tint) observe_body<1, false>(b->state.data(), b->gstate.data(), b->N, i, idx, b->H, SHAPES.s, records, round_over, last_winner);
-        else if (b->P == 1) observe_body<1, true>(b->state.data(), b->gstate.data(), b->N, i, idx, b->H, SHAPES.s, records, round_over, last_winner);
-        else if (!b->tint) observe_body<2, false>(b->state.data(), b->gstate.data(), b->N, i, idx, b->H, SHAPES.s, records, round_over, last_winner);
-        else observe_body<2, true>(b->state.data(), b->gstate.data(), b->N, i, idx, b->H, SHAPES.s, records, round_over, last_winner);
+        const Geo geo = geo_of_batch(b);
+        if (b->P == 1 && !b->tint) observe_body<1, false>(geo, i, idx, b->H, SHAPES.s, records, round_over, last_winner);
+        else if (b->P == 1) observe_body<1, true>(geo, i, idx, b->H, SHAPES.s, records, round_over, last_winner);
+        else if (!b->tint) observe_body<2, false>(geo, i, idx, b->H, SHAPES.s, records, round_over, last_winner);
+        else observe_body<2, true>(geo, i, idx, b->H, SHAPES.s, records, round_over, last_winner);
     }
     return TETRIS_OK;
 }
@@ -313,18 +332,18 @@ int tetris_observe_records(tetris_batch* b, const int32_t* idx, int n, tetris_re
 int tetris_snapshot(tetris_batch* b, const int32_t* idx, int n, uint32_t* blob) {
     int rc = check_idx(b, idx, n); if (rc) return rc;
     size_t total = (size_t)n * (NGWORDS + b->P * b->nw);
-    for (size_t t = 0; t < total; t++) snapshot_body(b->state.data(), b->gstate.data(), b->N, t, idx, b->P, blob, 0, b->nw);
+    for (size_t t = 0; t < total; t++) snapshot_body(geo_of_batch(b), t, idx, blob, 0);
     return TETRIS_OK;
 }
 int tetris_restore(tetris_batch* b, const int32_t* idx, int n, const uint32_t* blob) {
     int rc = check_idx(b, idx, n); if (rc) return rc;
     size_t total = (size_t)n * (NGWORDS + b->P * b->nw);
-    for (size_t t = 0; t < total; t++) snapshot_body(b->state.data(), b->gstate.data(), b->N, t, idx, b->P, (uint32_t*)blob, 1, b->nw);
+    for (size_t t = 0; t < total; t++) snapshot_body(geo_of_batch(b), t, idx, (uint32_t*)blob, 1);
     return TETRIS_OK;
 }
 int tetris_set_dead(tetris_batch* b, const int32_t* idx, int n, const uint8_t* dead) {
     int rc = check_idx(b, idx, n); if (rc) return rc;
-    for (int t = 0; t < n * b->P; t++) set_dead_body(b->state.data(), b->N, t, idx, b->P, dead);
+    for (int t = 0; t < n * b->P; t++) set_dead_body(geo_of_batch(b), t, idx, dead);
     return TETRIS_OK;
 }
 
@@ -332,8 +351,8 @@ int tetris_enumerate_drops(tetris_batch* b, const int32_t* idx, int n, const uin
                            uint8_t* cleared, uint32_t* after) {
     int rc = check_idx(b, idx, n); if (rc) return rc;
     for (size_t t = 0; t < (size_t)n * 40; t++) {
-        if (b->P == 1) enumerate_body<1>(b->state.data(), b->N, t, idx, player, b->H, SHAPES.s, valid, land_y, cleared, after, t);
-        else enumerate_body<2>(b->state.data(), b->N, t, idx, player, b->H, SHAPES.s, valid, land_y, cleared, after, t);
+        if (b->P == 1) enumerate_body<1>(geo_of_batch(b), t, idx, player, b->H, SHAPES.s, valid, land_y, cleared, after, t);
+        else enumerate_body<2>(geo_of_batch(b), t, idx, player, b->H, SHAPES.s, valid, land_y, cleared, after, t);
     }
     return TETRIS_OK;
 }
@@ -350,10 +369,10 @@ int tetris_get_actions(tetris_batch* b, const int32_t* idx, int n, const uint8_t
     const size_t lanes = (size_t)n * 40;
     std::vector<uint8_t> hc(lanes), hl(lanes * LANE_LISTS), hk(lanes * LANE_LISTS * max_keys);
     for (size_t t = 0; t < lanes; t++) {
-        if (b->P == 1) actions_body<1>(b->state.data(), b->N, t, idx, player, b->H, SHAPES.s, hc.data(), hl.data(), hk.data(), LANE_LISTS, max_keys, &b->status);
-        else actions_body<2>(b->state.data(), b->N, t, idx, player, b->H, SHAPES.s, hc.data(), hl.data(), hk.data(), LANE_LISTS, max_keys, &b->status);
+        if (b->P == 1) actions_body<1>(geo_of_batch(b), t, idx, player, b->H, SHAPES.s, hc.data(), hl.data(), hk.data(), LANE_LISTS, max_keys, b->flags);
+        else actions_body<2>(geo_of_batch(b), t, idx, player, b->H, SHAPES.s, hc.data(), hl.data(), hk.data(), LANE_LISTS, max_keys, b->flags);
     }
-    if (b->status & ST_BAD_ARGUMENT) { b->status &= ~(uint32_t)ST_BAD_ARGUMENT; return fail(TETRIS_E_ARG, "output capacity exceeded"); }
+    if (b->flags[F_BADARG]) { b->flags[F_BADARG] = 0; return fail(TETRIS_E_ARG, "output capacity exceeded"); }
     for (int i = 0; i < n; i++) {
         int total = 0;
         for (int xi = 0; xi < 10; xi++)
@@ -381,7 +400,7 @@ int tetris_observe_packed(tetris_batch* b, const int32_t* idx, int n, const uint
             size_t slot = idx ? (size_t)idx[i] : (size_t)i;
             int me = player ? player[i] : 0;
             int p = sl == 0 ? me : b->P - 1 - me;
-            piece[(size_t)sl * n + i] = (uint8_t)observe_board(b->state.data(), b->N, slot, b->P, p, b->H,
+            piece[(size_t)sl * n + i] = (uint8_t)observe_board(geo_of_batch(b), slot, p, b->H,
                                                                visual + ((size_t)sl * n + i) * cells, vector + ((size_t)sl * n + i) * 12);
         }
     return TETRIS_OK;
@@ -389,26 +408,35 @@ int tetris_observe_packed(tetris_batch* b, const int32_t* idx, int n, const uint
 int tetris_observe_packed_dev(tetris_batch* b, const int32_t* idx, int n, const uint8_t* player, uint8_t* visual, uint8_t* vector,
                               uint8_t* piece) { return tetris_observe_packed(b, idx, n, player, visual, vector, piece); }
 
-int tetris_rollout_random(tetris_batch* b, int launches, int steps_per_launch, uint32_t policy_seed, uint64_t first_step, int ms,
-                          uint64_t counters[4], float* elapsed_ms) {
+int tetris_rollout_launch(tetris_batch* b, int launches, int steps_per_launch, uint32_t policy_seed, uint64_t first_step, int ms,
+                          float* elapsed_ms) {
     if (launches < 1 || steps_per_launch < 0 || steps_per_launch > 256) return fail(TETRIS_E_ARG, "launches/steps_per_launch");
-    const int group = steps_per_launch ? 256 / steps_per_launch : 256;   // 0 = load/store only (diagnostic floor)
+    // the harness looks at the flag words after every launch, so the margin only has to cover one launch
     const uint32_t saved = b->margin;
-    b->margin = (uint32_t)(2 * group * steps_per_launch + 16);
+    b->margin = (uint32_t)(2 * steps_per_launch + 16);
     if (b->margin < saved) b->margin = saved;
     int rc = TETRIS_OK;
     for (int l = 0; l < launches && !rc; l++) {
         KArgs a = base_args(b, b->N, nullptr);
         a.ms = ms; a.steps = steps_per_launch; a.policy_seed = policy_seed;
         a.first_step = first_step + (uint64_t)l * (uint64_t)steps_per_launch;
-        LaneCounters c;
-        run<M_ROLLOUT>(b, a, &c);
-        if (counters) { counters[0] += c.steps; counters[1] += c.episodes; counters[2] += c.lines; counters[3] += c.sent; }
-        if ((l + 1) % group == 0 || l + 1 == launches) rc = finish_call(b);
+        run<M_ROLLOUT>(b, a);
+        rc = finish_call(b);
     }
     b->margin = saved;
     if (elapsed_ms) *elapsed_ms = 0.0f;
     return rc;
+}
+
+int tetris_rollout_random(tetris_batch* b, int launches, int steps_per_launch, uint32_t policy_seed, uint64_t first_step, int ms,
+                          uint64_t counters[4], float* elapsed_ms) {
+    uint64_t before[4], after[4];
+    tetris_rollout_totals(b, before);
+    int rc = tetris_rollout_launch(b, launches, steps_per_launch, policy_seed, first_step, ms, elapsed_ms);
+    if (rc) return rc;
+    tetris_rollout_totals(b, after);
+    if (counters) for (int k = 0; k < 4; k++) counters[k] += after[k] - before[k];
+    return TETRIS_OK;
 }
 
 // test-only: reads (and clears) the key-interpreter path counters of tetris_engine.h

@@ -356,7 +356,7 @@ def test_colour_batch_matches_oracle_cells(kind):
             max_gc = max(max_gc, int(b["garbage_cleared"].max()))
         if s == 100:
             blob = eng.snapshot()
-            assert blob.shape[1] == 4 + P * 69
+            assert blob.shape[1] == 5 + P * 69
         idx = np.nonzero(d2)[0].astype(np.int32)
         if len(idx):
             episode[idx] += 1

@@ -135,9 +135,11 @@ def test_split_rollout_equals_oracle_two_player_rollout(tmp_path):
     rec, ro, lw = ref.observe()
     got = [np.load(os.path.join(str(tmp_path), f"roll{s}.npz")) for s in (0, 1)]
     episodes, lines, sent = int(want[1]), int(want[2]), int(want[3])
-    assert int(got[0]["totals"][0]) == episodes == int(got[1]["totals"][0]) and episodes > 0
-    assert int(got[0]["totals"][1]) + int(got[1]["totals"][1]) == lines
-    assert int(got[0]["totals"][2]) + int(got[1]["totals"][2]) == sent
+    # totals = {env-steps counted on the device, episodes, lines, sent}; steps and episodes are per game (both sides count them)
+    assert int(got[0]["totals"][0]) == int(want[0]) == int(got[1]["totals"][0]) == N * STEPS_ROLLOUT
+    assert int(got[0]["totals"][1]) == episodes == int(got[1]["totals"][1]) and episodes > 0
+    assert int(got[0]["totals"][2]) + int(got[1]["totals"][2]) == lines
+    assert int(got[0]["totals"][3]) + int(got[1]["totals"][3]) == sent
     for side in (0, 1):
         for f in FIELDS:
             assert np.array_equal(got[side]["rec"][f][:, 0], rec[f][:, side]), (side, f)

@@ -133,8 +133,9 @@ def test_split_rollout_kernels_on_gpu_match_oracle_rollout():
     _, want = ref.rollout_random(STEPS, threads=8)
     rec, ro, lw = ref.observe()
     t0, t1 = results[0][1], results[1][1]
-    assert int(t0[0]) == int(want[1]) == int(t1[0])
-    assert int(t0[1]) + int(t1[1]) == int(want[2]) and int(t0[2]) + int(t1[2]) == int(want[3])
+    assert int(t0[0]) == int(want[0]) == int(t1[0]) == N * STEPS          # env-steps, counted on the device
+    assert int(t0[1]) == int(want[1]) == int(t1[1])
+    assert int(t0[2]) + int(t1[2]) == int(want[2]) and int(t0[3]) + int(t1[3]) == int(want[3])
     for side in (0, 1):
         got, gro, glw = results[side][0]
         for f in base.FIELDS:
