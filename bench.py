@@ -10,9 +10,11 @@ For N>1 (launched by torch.distributed.run, one rank per GPU) every rank owns it
 games never interact across ranks, so there is no data-path collective ("scaling": "weak").
 
 Prints ONE JSON line (rank 0).  `value` = env-steps of all ranks / max-over-ranks wall time of the
-K timed launches, inputs resident in HBM.  `roofline` prices the step kernel against the 8 TB/s HBM
-roofline with SURVEY §8(d)'s algorithmic bytes (389 B per 1-player env-step, 774 B per 2-player one)
-and the kernel's average launch duration measured with HIP events on the launch stream.
+K timed launches, inputs resident in HBM; nothing but the K step-kernel launches lies inside that
+region (counters are summed by a separate kernel before and after it).  `roofline` prices the step
+kernel against the 8 TB/s HBM roofline with SURVEY §8(d)'s algorithmic bytes (389 B per 1-player
+env-step, 774 B per 2-player one) over the SAME wall clock as `value`; `launch_us_events` /
+`frac_kernel` give the same two figures from HIP events on the launch stream.
 `cpu_baseline` times the reference C++ backend itself (oracle/_ref, built in the container from
 /root/reference) or, without it, the C restatement, on the host cores of this box.
 """
@@ -173,6 +175,7 @@ def main():
     ge.package()
     import importlib
     sharded = importlib.import_module("drl-tetris_amd.distributed")
+    capi = importlib.import_module("drl-tetris_amd.capi")
     if args.workload == "split":
         return bench_split(args, sharded, dist, rank, world, local_rank)
     N, P, S = args.games, args.players, args.steps_per_launch
@@ -188,18 +191,40 @@ def main():
     batch = shard
 
     if rank == 0:
+        # env-steps are COUNTED by the step kernels (one increment per game and step in a per-game word, summed by a separate
+        # kernel before and after the timed region): the comparison below is a check of the device, not of the host's arithmetic
         env_steps = int(counters[0])
-        assert env_steps == world * N * S * args.steps, (env_steps, world, N, S, args.steps)
-        launch_us = (ev_ms if ev_ms > 0 else wall * 1e3) * 1e3 / args.steps   # HIP events on the launch stream (the CPU rehearsal library has none: wall clock)
-        algo_bytes = ALGO_BYTES[P] * N * S                        # per launch, per GPU
-        achieved = algo_bytes / (launch_us * 1e-6) / 1e9
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", f"pmc_p{P}_s{S}.json")
-        if os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        assert env_steps == world * N * S * args.steps, ("env-steps counted on the device differ from launches*S*N", env_steps, world, N, S, args.steps)
+        # ONE clock for value and roofline.frac: the wall clock around the K launches (barrier + synchronize on both sides).
+        # The HIP events around the same K launches on the launch stream are reported beside it (`launch_us_events`,
+        # `frac_kernel`); with nothing but the step kernels inside the region the two agree to a few per cent.
+        launch_us = wall * 1e6 / args.steps
+        launch_us_events = ev_ms * 1e3 / args.steps if ev_ms > 0 else None     # (the CPU rehearsal library has no events)
+        lib_path = os.path.abspath(os.environ.get("BENCH_LIB_PATH") or ge.LIB)
+        roofline = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "kernel": "k_duo<M_ROLLOUT>" if (P == 2 and S == 1) else f"k_game<{P}, M_ROLLOUT>",
+                    "launch_us": launch_us, "launch_us_events": launch_us_events, "clock": "wall (same clock as `value`)"}
+        if S == 1:
+            algo_bytes = ALGO_BYTES[P] * N                            # per launch, per GPU: SURVEY §8(d) bytes x games
+            achieved = algo_bytes / (launch_us * 1e-6) / 1e9
+            roofline.update({"achieved": achieved, "frac": achieved / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": algo_bytes,
+                             "frac_kernel": (algo_bytes / (launch_us_events * 1e-6) / 1e9 / HBM_PEAK_GBS) if launch_us_events else None})
+            # HBM traffic cannot be measured inside this process: it comes from separate rocprofv3 --pmc passes over this same
+            # command (profiles/pmc_passes.sh), corrected as MI355X_MICROARCH.md prescribes; the file is named next to the number
+            pmc = os.path.join(ROOT, "profiles", "r02", f"pmc_p{P}_s{S}.json")
+            traffic, source = None, None
+            if os.path.exists(pmc):
+                try:
+                    traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                    source = os.path.relpath(pmc, ROOT) + " (separate rocprofv3 --pmc passes of this command: FETCH_SIZE x 2 + WRITE_SIZE per launch)"
+                except Exception:
+                    traffic = None
+            roofline.update({"traffic": traffic, "traffic_source": source})
+        else:
+            # a fused launch keeps the state in registers for S steps: SURVEY's per-step byte budget does not apply, and a
+            # fraction of the HBM roofline would say nothing about it
+            roofline.update({"achieved": None, "frac": None, "frac_kernel": None, "traffic": None,
+                             "note": f"{S} env-steps fused per launch: state is loaded and stored once per launch, no per-step HBM roofline applies"})
         line = {
             "metric": "env-steps/sec at 64k parallel 20x10 boards",
             "value": env_steps / wall,
@@ -218,12 +243,11 @@ def main():
                             f"random (rotation,translation) policy, auto-reset, {S} env-step(s) per launch",
                 "games_per_gpu": N, "players": P, "steps_per_launch": S, "parallelism": f"replicas x{world} (no collective)",
             },
-            "roofline": {
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic, "kernel": "k_duo<M_ROLLOUT>" if (P == 2 and S == 1) else f"k_game<{P}, M_ROLLOUT>", "algorithmic_bytes_per_launch": algo_bytes,
-                "launch_us": launch_us,
-            },
+            "roofline": roofline,
+            "env_steps_counted_on_device": env_steps,
             "episodes": int(counters[1]), "lines_cleared": int(counters[2]), "garbage_sent": int(counters[3]),
+            "library": os.path.relpath(lib_path, ROOT) if lib_path.startswith(ROOT) else lib_path,
+            "device": capi.device_name(local_rank, os.environ.get("BENCH_LIB_PATH")),
         }
         if args.cpu_seconds > 0 and world == 1:
             line["cpu_baseline"] = cpu_baseline(P, args.height, args.cpu_seconds)

@@ -44,6 +44,7 @@ _libs = {}
 _SIGNATURES = {
     "tetris_last_error": (C.c_char_p, []),
     "tetris_device_count": (C.c_int, []),
+    "tetris_device_name": (C.c_int, [C.c_int, C.c_char_p, C.c_int]),
     "tetris_record_size": (C.c_int, []),
     "tetris_layout_words": (C.c_int, []),
     "tetris_snapshot_words": (C.c_int, [C.c_void_p]),
@@ -126,6 +127,12 @@ def load_library(lib_path=None):
         raise TetrisError("tetris_record layout mismatch between the library and capi.RECORD")
     _libs[path] = lib
     return lib
+
+
+def device_name(device=0, lib_path=None):
+    buf = C.create_string_buffer(256)
+    rc = load_library(lib_path).tetris_device_name(int(device), buf, 256)
+    return buf.value.decode() if rc == 0 else "unknown"
 
 
 def _p(a):
@@ -232,6 +239,15 @@ class TetrisBatch:
         dead = np.zeros((n, self.n_players), np.uint8)
         self._check(self.lib.tetris_step_rt(self._h, _p(rot), _p(trans), _p(pl), int(ms), _p(done), _p(lines), _p(dead)))
         return (done, lines, dead) if full else done
+
+    def step_rt_dev(self, rot, trans, player, done, lines, dead, ms=400, auto_reset=False):
+        """tetris_step_rt_dev_ex: every argument is a raw DEVICE address (int / c_void_p) or None; only enqueues.
+        auto_reset: finished games are reset inside the launch with the next seed of the built-in schedule."""
+        self._check(self.lib.tetris_step_rt_dev_ex(self._h, rot, trans, player, int(ms), done, lines, dead, 1 if auto_reset else 0))
+
+    def reset_dev(self, mask=None, seeds=None):
+        """tetris_reset_dev: device mask [N] (None = all games), device seeds int16 [N] (None = built-in schedule); only enqueues."""
+        self._check(self.lib.tetris_reset_dev(self._h, mask, seeds))
 
     def observe(self, idx=None):
         a, n = self._idx(idx)

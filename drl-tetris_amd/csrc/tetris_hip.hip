@@ -626,6 +626,14 @@ int tetris_device_count(void) {
     return n;
 }
 
+int tetris_device_name(int device, char* buf, int len) {
+    if (!buf || len < 1) return fail(TETRIS_E_ARG, "buf/len");
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    snprintf(buf, (size_t)len, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    return TETRIS_OK;
+}
+
 int tetris_record_size(void) { return (int)sizeof(tetris_record); }
 int tetris_layout_words(void) { return NWORDS; }
 int tetris_snapshot_words(const tetris_batch* b) { return b ? NGWORDS + b->P * b->nw : 0; }

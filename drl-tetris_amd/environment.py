@@ -117,6 +117,7 @@ class tetris_environment_vector:
         for a in actions:
             assert type(a) is action, f"perform_action(action a, int p) was called with type(action)={type(a)}"
         length = np.fromiter(map(len, actions), np.int64, n)
+        assert int(length.max(initial=0)) <= 255, "an action may hold at most 255 keys (uint8 length on the device)"
         total = int(length.sum())
         keys = np.zeros((n, self.n_players, max(1, int(length.max(initial=0)))), np.uint8)
         lens = np.ones((n, self.n_players), np.uint8)          # the other players get the null action [0]
@@ -154,7 +155,17 @@ class tetris_environment_vector:
         self.done[idx] = done_b
         zero = self._shared_zero
         rewards = [zero] * n
-        for j in np.nonzero(done_b)[0]:
+        if self.settings["extra_rewards"]:
+            # tetris_environment.py:144-149: two components, [w_base * win/lose signal, w_combo * my combo count], every step
+            w_base, w_combo = self.settings["reward_ammount"]
+            combo = self.backend.observe_packed(idx, np.asarray(players, np.uint8))[1][0][:, 4]
+            for j in range(n):
+                i, p = idx[j], players[j]
+                r = maingoal_reward([w_base * self._reward(bool(done_b[j]), dead[j], p), w_combo * int(combo[j])])
+                rewards[j] = r
+                self.round_reward[i][p] = self.round_reward[i][p] + r
+                self.tot_reward[i][p] = self.tot_reward[i][p] + r
+        for j in (() if self.settings["extra_rewards"] else np.nonzero(done_b)[0]):
             i, p = idx[j], players[j]
             base = self._reward(True, dead[j], p)
             if base != 0:

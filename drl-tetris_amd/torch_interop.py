@@ -26,13 +26,25 @@ class TorchEnv:
     def _ptr(self, t):
         return None if t is None else C.c_void_p(t.data_ptr())
 
-    def step_rt(self, rot, trans, player=None, ms=400):
-        """rot/trans/player: uint8 device tensors [n].  -> (done [n], lines [P,n], dead [P,n]) device tensors (reused)."""
+    def step_rt(self, rot, trans, player=None, ms=400, auto_reset=False):
+        """rot/trans/player: uint8 device tensors [n].  -> (done [n], lines [P,n], dead [P,n]) device tensors (reused).
+        auto_reset=True: games whose round ended are reset inside the same launch (drl_tetris/worker.py:157-166 without the
+        host round trip; seed schedule of include/tetris_hip.h); the outputs describe the step BEFORE the reset.  Nothing in
+        this call waits for the GPU: a rollout loop of observe -> policy -> step_rt(auto_reset=True) runs without a host sync."""
         for t in (rot, trans) + (() if player is None else (player,)):
             assert t.dtype == self.torch.uint8 and t.is_cuda and t.is_contiguous() and t.numel() == self.b.n_games
-        self.b._check(self.b.lib.tetris_step_rt_dev(self.b._h, self._ptr(rot), self._ptr(trans), self._ptr(player), int(ms),
-                                                   self._ptr(self.done), self._ptr(self.lines), self._ptr(self.dead)))
+        self.b.step_rt_dev(self._ptr(rot), self._ptr(trans), self._ptr(player), self._ptr(self.done), self._ptr(self.lines),
+                           self._ptr(self.dead), ms=ms, auto_reset=auto_reset)
         return self.done, self.lines, self.dead
+
+    def reset(self, mask=None, seeds=None):
+        """Device-side reset: mask uint8 [n] device tensor (non-zero = reset; None = all), seeds int16 [n] device tensor
+        (None = the built-in schedule).  Only enqueues."""
+        if mask is not None:
+            assert mask.dtype == self.torch.uint8 and mask.is_cuda and mask.is_contiguous() and mask.numel() == self.b.n_games
+        if seeds is not None:
+            assert seeds.dtype == self.torch.int16 and seeds.is_cuda and seeds.is_contiguous() and seeds.numel() == self.b.n_games
+        self.b.reset_dev(self._ptr(mask), self._ptr(seeds))
 
     def observe(self, player=None):
         """-> visual [S,n,H,W], vector [S,n,12], piece [S,n] uint8 device tensors; slot 0 = `player`'s own board."""

@@ -67,6 +67,7 @@ typedef struct tetris_batch tetris_batch;
 
 const char *tetris_last_error(void);
 int         tetris_device_count(void);                 /* < 0 on error                          */
+int         tetris_device_name(int device, char *buf, int len);   /* "<name> (<arch>, <n> CUs)"  */
 int         tetris_record_size(void);
 int         tetris_snapshot_words(const tetris_batch *b);   /* uint32 words per game in a snapshot */
 

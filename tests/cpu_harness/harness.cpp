@@ -7,6 +7,7 @@
 // against the oracle in a container that has no GPU.  Only tests/ loads this library, always by
 // explicit path; the product binding (drl-tetris_amd/capi.py) loads libtetris_hip.so and nothing else.
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -157,6 +158,7 @@ extern "C" {
 
 const char* tetris_last_error(void) { return g_err.c_str(); }
 int tetris_device_count(void) { return 0; }
+int tetris_device_name(int, char* buf, int len) { if (buf && len > 0) snprintf(buf, (size_t)len, "cpu test harness (g++ build of the kernel bodies, no GPU)"); return TETRIS_OK; }
 int tetris_record_size(void) { return (int)sizeof(tetris_record); }
 int tetris_layout_words(void) { return NWORDS; }
 int tetris_snapshot_words(const tetris_batch* b) { return b ? NGWORDS + b->P * b->nw : 0; }

@@ -31,9 +31,17 @@ def _check(line, world, games, steps, warmup, spl):
     assert "workload" in line["config"] and "model" not in line["config"]
     # whole-job aggregate: all ranks' env-steps over the max-over-ranks time of exactly `steps` launches
     assert abs(line["value"] - world * games * spl / (line["ms_per_step"] * 1e-3)) <= 1e-6 * line["value"]
+    assert line["env_steps_counted_on_device"] == world * games * spl * steps
+    assert line["library"].endswith(".so") and line["device"]         # a BENCH_LIB_PATH run identifies itself
     r = line["roofline"]
-    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
-    assert r["algorithmic_bytes_per_launch"] == 389 * games * spl
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    if spl == 1:
+        # value and roofline.frac come from ONE clock: value x 389 B / 8 TB/s IS the fraction
+        assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+        assert r["algorithmic_bytes_per_launch"] == 389 * games
+        assert abs(r["frac"] - line["value"] / world * 389 / 8e12) <= 1e-9 * r["frac"]
+    else:
+        assert r["frac"] is None and r["achieved"] is None           # fused launches: no per-step HBM roofline
 
 
 def test_single_process_line_with_cpu_baseline():

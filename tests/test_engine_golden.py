@@ -8,17 +8,36 @@ from tests import engines, replay
 FIELDS = replay.VISIBLE + replay.HIDDEN
 
 
-@pytest.mark.parametrize("kind", engines.ENGINE_PARAMS)
 @pytest.mark.parametrize("name", replay.trace_names())
-def test_engine_replays_reference_trace(kind, name):
+def test_engine_replays_reference_trace(name):
+    """Every trace on its own, full length, through a 1-game batch of the CPU harness build (the HIP path replays the same
+    traces at full length as the games of one batch per geometry: test_all_traces_full_length_in_one_batch)."""
     trace = replay.load_trace(name)
-    max_events = None if kind == "harness" or name in ("greedy_2p", "keys_2p", "greedy_1p", "drop_2p", "rt_2p_sz", "garbage_flood_2p_12") else 700
 
     def factory(P, H, W, pieces, seed):
-        return engines.make(kind, 1, P, H, pieces, seeds=seed)
+        return engines.make("harness", 1, P, H, pieces, seeds=seed)
 
-    n = replay.replay(trace, factory, fields=FIELDS, occupancy_only=True, max_events=max_events, check_actions=True)
+    n = replay.replay(trace, factory, fields=FIELDS, occupancy_only=True, check_actions=True)
     assert n > 0
+
+
+GROUPS = sorted(replay.trace_groups().items())
+
+
+@pytest.mark.parametrize("kind", engines.ENGINE_PARAMS)
+@pytest.mark.parametrize("colours", [False, True])
+@pytest.mark.parametrize("key,names", GROUPS, ids=["-".join(names) for _, names in GROUPS])
+def test_all_traces_full_length_in_one_batch(kind, colours, key, names):
+    """All 18 reference traces at FULL length (no event cut): the traces of one geometry are the games of ONE batch, so every
+    event index is one reset call + one make/finish pair + one observe for all of them — 30 000 reference events through
+    the batched entry points with index lists, `get_actions` lists included where the reference recorded them.  With
+    colours: State.field values 0..8 and garbageCleared exactly (gamePlay.cpp:146,202; gameField.cpp:120-145)."""
+    def factory(n, P, H, W, pieces, seeds):
+        return engines.make(kind, n, P, H, pieces, seeds=seeds, colours=colours)
+
+    pairs = replay.replay_batch(names, factory, fields=FIELDS + (replay.COLOUR_ONLY if colours else []), occupancy_only=not colours,
+                                check_actions=not colours)
+    assert pairs == sum(len(replay.load_trace(n)["ev_kind"]) for n in names)
 
 
 @pytest.mark.parametrize("kind", engines.ENGINE_PARAMS)
@@ -32,7 +51,7 @@ def test_colour_planes_give_the_reference_field_values(kind, name):
         return engines.make(kind, 1, P, H, pieces, seeds=seed, colours=True)
 
     n = replay.replay(trace, factory, fields=FIELDS + replay.COLOUR_ONLY, occupancy_only=False,
-                      max_events=None if kind == "harness" else 1200)
+                      max_events=None if kind == "harness" else 300)
     assert n > 0
 
 

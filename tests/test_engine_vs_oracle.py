@@ -182,6 +182,100 @@ def test_simulate_without_finalize_and_snapshot_restore(kind):
     engines.assert_same_state(eng, ref, where="locked state does not move")
 
 
+class _DevArrays:
+    """uint8 / int16 arrays the `_dev` entry points can take: numpy for the CPU harness (its "device" is host memory),
+    torch tensors on the GPU."""
+
+    def __init__(self, kind):
+        self.gpu = kind == "hip"
+        if self.gpu:
+            import torch
+            self.torch = torch
+
+    def put(self, a):
+        return self.torch.as_tensor(np.ascontiguousarray(a)).cuda() if self.gpu else np.ascontiguousarray(a).copy()
+
+    def ptr(self, t):
+        import ctypes as C
+        if t is None:
+            return None
+        return C.c_void_p(t.data_ptr()) if self.gpu else t.ctypes.data_as(C.c_void_p)
+
+    def get(self, t):
+        return t.cpu().numpy() if self.gpu else t.copy()
+
+
+@pytest.mark.parametrize("kind", engines.ENGINE_PARAMS)
+@pytest.mark.parametrize("P", [1, 2])
+def test_device_side_auto_reset_and_masked_reset(kind, P):
+    """tetris_step_rt_dev_ex(TETRIS_STEP_AUTO_RESET) and tetris_reset_dev against the oracle driven the way the reference's
+    worker loop drives its envs (worker.py:157-166: step, then reset the finished ones): 200 steps, the outputs of every step
+    (done / lines / dead BEFORE the reset) and the complete state; seeds follow the built-in schedule by game and episode."""
+    n = 4096 if kind == "hip" else 320
+    eng, ref = _pair(kind, n, P)
+    eng.set_game_offset(1000)                                  # the schedule is keyed by GLOBAL game id
+    D = _DevArrays(kind)
+    rng = np.random.default_rng(11 + P)
+    episode = np.zeros(n, np.int64)
+    done_d, lines_d, dead_d = D.put(np.zeros(n, np.uint8)), D.put(np.zeros((P, n), np.uint8)), D.put(np.zeros((P, n), np.uint8))
+    total_done = 0
+    for s in range(200):
+        rot, trans = rng.integers(0, 4, n).astype(np.uint8), rng.integers(0, 10, n).astype(np.uint8)
+        player = rng.integers(0, P, n).astype(np.uint8)
+        auto = s % 50 < 40                                     # mostly auto-reset; sometimes a separate masked reset launch
+        r_d, t_d, p_d = D.put(rot), D.put(trans), D.put(player)
+        eng.step_rt_dev(D.ptr(r_d), D.ptr(t_d), D.ptr(p_d), D.ptr(done_d), D.ptr(lines_d), D.ptr(dead_d), auto_reset=auto)
+        if not auto:
+            eng.reset_dev(D.ptr(done_d), None)                 # mask = this step's done flags, seeds from the schedule
+        d_ref = ref.step_rt(rot, trans, player)
+        rec = ref.observe()[0]
+        if kind == "hip":
+            eng.sync()
+        assert np.array_equal(D.get(done_d), d_ref), s
+        assert np.array_equal(D.get(lines_d).T, rec["reward"]) and np.array_equal(D.get(dead_d).T, rec["dead"]), s
+        idx = np.nonzero(d_ref)[0].astype(np.int32)
+        total_done += len(idx)
+        if len(idx):
+            episode[idx] += 1
+            ref.reset(idx, orc.episode_seed(idx + 1000, episode[idx]))
+        if s % 25 == 24:
+            engines.assert_same_state(eng, ref, where=f"step {s}")
+    assert total_done > n                                      # every game was reset on the device more than once on average
+    # explicit device seeds for a masked subset
+    mask = (np.arange(n) % 3 == 0).astype(np.uint8)
+    seeds = rng.integers(-32768, 32767, n).astype(np.int16)
+    m_d, s_d = D.put(mask), D.put(seeds)
+    eng.reset_dev(D.ptr(m_d), D.ptr(s_d))
+    idx = np.nonzero(mask)[0].astype(np.int32)
+    ref.reset(idx, seeds[idx])
+    engines.assert_same_state(eng, ref, where="masked reset with device seeds")
+
+
+@pytest.mark.parametrize("kind", engines.ENGINE_PARAMS)
+def test_device_driven_loop_outlives_the_resident_rng_tables(kind):
+    """An asynchronous `_dev` loop whose episodes outlive the resident RNG-table chunks (2 x 624 draws): O pieces laid side
+    by side clear two rows every five pieces, so the games never end.  Nothing in the loop synchronises; the request to
+    extend the tables reaches the host through the batch's flag words (include/tetris_hip.h) and must be answered before any
+    board runs past the tables."""
+    n, P, steps = 256, 1, 1500
+    seeds = orc.episode_seed(np.arange(n), 0)
+    eng = engines.make(kind, n, P, 20, (6,), seeds=seeds)
+    ref = engines.make("oracle", n, P, 20, (6,), seeds=seeds)
+    D = _DevArrays(kind)
+    rot = np.zeros(n, np.uint8)
+    r_d = D.put(rot)
+    t_ds = [D.put(np.full(n, 2 * k, np.uint8)) for k in range(5)]
+    done_d = D.put(np.zeros(n, np.uint8))
+    for s in range(steps):
+        eng.step_rt_dev(D.ptr(r_d), D.ptr(t_ds[s % 5]), None, D.ptr(done_d), None, None, auto_reset=True)
+        d = ref.step_rt(rot, np.full(n, 2 * (s % 5), np.uint8))
+        assert not d.any()
+    eng.sync()
+    assert eng.table_chunks >= 3
+    engines.assert_same_state(eng, ref, where="end")
+    assert int(ref.observe()[0]["piece_draws"].min()) > 1248
+
+
 @pytest.mark.parametrize("kind", engines.ENGINE_PARAMS)
 def test_rng_tables_extend_past_two_chunks(kind):
     """An episode that outlives the resident RNG-table chunks (624 draws each): key [1] never locks, so

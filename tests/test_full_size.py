@@ -42,6 +42,46 @@ def test_64k_boards_long_fused_rollout_bit_exact(P, steps, fused):
         engines.assert_same_state(eng, ref, idx=idx, where=f"games {lo}..")
 
 
+def test_c4_enumerate_16384_boards_at_step_12():
+    """BASELINE config 4 at its full size: 16 384 single-player boards taken at step 12 of their first episode
+    under the synthetic policy (auto-reset inside), all 4 x 10 (rotation, column) drop afterstates of every board — validity,
+    landing row, rows a finalize would clear and the stamped board's columns — against the oracle's cell-based enumeration
+    (TestField.cpp:64-125)."""
+    n = 16384
+    seeds = orc.episode_seed(np.arange(n), 0)
+    eng = engines.make("hip", n, 1, seeds=seeds)
+    ref = engines.make("oracle", n, 1, seeds=seeds)
+    c_gpu, _ = eng.rollout_random(12, 1)
+    _, c_ref = ref.rollout_random(12, threads=min(32, len(os.sched_getaffinity(0))))
+    assert c_gpu.tolist() == c_ref.tolist()
+    v1, y1, c1, a1 = eng.enumerate_drops()
+    v2, y2, c2, a2 = ref.enumerate_drops()
+    assert np.array_equal(v1, v2)
+    ok = v2.astype(bool)
+    assert np.array_equal(y1[ok], y2[ok]) and np.array_equal(c1[ok], c2[ok])          # rows with valid == 0 are unspecified
+    for lo in range(0, n, 2048):                           # columns -> cells: bit y of column c = cell (y, c)
+        sl = slice(lo, lo + 2048)
+        cells = ((a1[sl][..., None, :] >> np.arange(20, dtype=np.uint32)[:, None]) & 1).astype(bool)     # [n,4,10,20,10]
+        assert np.array_equal(cells[ok[sl]], a2[sl][ok[sl]] > 0)
+    assert 0.4 < ok.mean() < 0.8 and c2[ok].max() >= 1
+    # the device-resident form an agent consumes (no host copies): same numbers
+    import ctypes as C
+
+    import torch
+    dev = torch.device("cuda", 0)
+    d_valid = torch.zeros(n * 40, dtype=torch.uint8, device=dev)
+    d_land = torch.zeros(n * 40, dtype=torch.int8, device=dev)
+    d_clr = torch.zeros(n * 40, dtype=torch.uint8, device=dev)
+    d_after = torch.zeros(n * 40 * 10, dtype=torch.int32, device=dev)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    eng._check(eng.lib.tetris_enumerate_drops_dev(eng._h, None, n, None, p(d_valid), p(d_land), p(d_clr), p(d_after)))
+    eng.sync()
+    assert np.array_equal(d_valid.cpu().numpy().reshape(n, 4, 10), v2)
+    assert np.array_equal(d_land.cpu().numpy().reshape(n, 4, 10)[ok], y2[ok])
+    assert np.array_equal(d_clr.cpu().numpy().reshape(n, 4, 10)[ok], c2[ok])
+    assert np.array_equal(d_after.cpu().numpy().view(np.uint32).reshape(n, 4, 10, 10)[ok], a1[ok])
+
+
 def test_batch_independence_and_order_invariance():
     """Games never interact: stepping a permuted / split batch gives the same per-game results
     (the property that makes sharding across GPUs collective-free)."""

@@ -102,13 +102,16 @@ def test_split_kernels_on_gpu_match_colocated_oracle(scenario, pieces):
         assert np.array_equal(gro, ro) and np.array_equal(glw, lw)
 
 
-def test_split_rollout_kernels_on_gpu_match_oracle_rollout():
-    """Device-driven split rollout (policy + auto-reset inside the split kernels) on the GPU, both sides in one process."""
+@pytest.mark.parametrize("N,STEPS", [(4096, 160), (65536, 96)], ids=["4096x160", "c5_per_gpu_size_65536x96"])
+def test_split_rollout_kernels_on_gpu_match_oracle_rollout(N, STEPS):
+    """Device-driven split rollout (policy + auto-reset inside the split kernels) on the GPU, both sides in one process.
+    The second case is BASELINE config 5's per-GPU size: 65 536 games per side (each side = what one GPU of the 8 holds),
+    96 steps, counters and EVERY board of both sides against the oracle's co-located two-player rollout on all host cores."""
     import importlib
+    import os
 
     import tests.test_split_opponents_gloo as base
     mod = importlib.import_module("drl-tetris_amd.distributed")
-    N, STEPS = 4096, 160
     tg = ThreadGather(2)
     results, errors = {}, []
 
@@ -130,7 +133,7 @@ def test_split_rollout_kernels_on_gpu_match_oracle_rollout():
         t.join()
     assert not errors, errors
     ref = orc.OracleBatch(N, 2, 20, 10, seeds=orc.episode_seed(np.arange(N), 0))
-    _, want = ref.rollout_random(STEPS, threads=8)
+    _, want = ref.rollout_random(STEPS, threads=min(32, len(os.sched_getaffinity(0))))
     rec, ro, lw = ref.observe()
     t0, t1 = results[0][1], results[1][1]
     assert int(t0[0]) == int(want[0]) == int(t1[0]) == N * STEPS          # env-steps, counted on the device
