@@ -68,6 +68,7 @@ _SIGNATURES = {
     "tetris_set_dead": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "tetris_enumerate_drops": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "tetris_enumerate_drops_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "tetris_enumerate_drops_dev_ex": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "tetris_timer_start": (C.c_int, [C.c_void_p]),
     "tetris_timer_stop": (C.c_int, [C.c_void_p, C.c_void_p]),
     "tetris_get_actions": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
@@ -296,6 +297,11 @@ class TetrisBatch:
         after = np.zeros((n, 4, 10, 10), np.uint32) if columns else None
         self._check(self.lib.tetris_enumerate_drops(self._h, _p(a), n, _p(pl), _p(valid), _p(land), _p(cleared), _p(after)))
         return valid, land, cleared, after
+
+    def enumerate_drops_dev(self, n, valid, land_y, cleared, after=None, idx=None, player=None, planar=False):
+        """tetris_enumerate_drops_dev_ex: raw DEVICE addresses (int / c_void_p) or None; only enqueues.
+        planar: `after` is [10][n*40] (one column plane after the other) instead of [n*40][10]."""
+        self._check(self.lib.tetris_enumerate_drops_dev_ex(self._h, idx, int(n), player, valid, land_y, cleared, after, 1 if planar else 0))
 
     def get_actions(self, idx=None, player=None, max_lists=64, max_keys=48):
         """The reference's ordered key lists per game (PythonHandle.get_actions; masks[p].action).

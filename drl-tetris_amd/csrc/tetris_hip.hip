@@ -85,7 +85,8 @@ __global__ __launch_bounds__(256) void k_duo(KArgs a) {
     const int gi = wave * 32 + (lane & 31);
     const bool active = gi < a.n;
     constexpr bool ROLL = MODE == M_ROLLOUT, AUTO = MODE == M_STEP_RT_AUTO;
-    const Geo geo = geo_of(a);
+    Geo geo = geo_of(a);
+    geo.P = 2;                           // compile-time stride factor for the hot loads
     const Ref gr = game_ref(geo, (size_t)gi), br = board_ref(geo, side, (size_t)gi);
     Game<1> g;
     Player& q = g.pl[0];
@@ -303,12 +304,57 @@ __global__ __launch_bounds__(BLOCK) void k_observe_packed(Geo geo, int n, const 
     }
 }
 
-template <int P>
-__global__ __launch_bounds__(256) void k_enumerate(Geo geo, int n, const int32_t* idx,
-                                                   const uint8_t* player, int H, uint8_t* valid, int8_t* land_y,
-                                                   uint8_t* cleared, uint32_t* after) {
-    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < (size_t)n * 40) enumerate_body<P>(geo, t, idx, player, H, d_shape_table.s, valid, land_y, cleared, after, t);
+// BASELINE config 4.  One workgroup = ENUM_BOARDS boards x 40 placement lanes.  Phase A: lanes 0..10 of a board fetch its ten
+// columns and piece word (ONE global load per word and board instead of one per placement).  Phase B: the board's lanes fill
+// its BoardPre in LDS (tetris_kernels.h) — band window and depth strip by the column lanes (LDS atomics / byte writes),
+// prefix / suffix ANDs by lanes 10..31.  Phase C: every lane places its (rotation, column) from ~10 LDS reads.
+// PLANAR: after[c][lanes] — store c of a wave is 256 contiguous bytes; else after[lane][10] as tetris_enumerate_drops documents.
+template <int P, bool PLANAR>
+__global__ __launch_bounds__(ENUM_BLOCK) void k_enumerate(Geo geo, int n, const int32_t* idx, const uint8_t* player, int H,
+                                                          uint8_t* valid, int8_t* land_y, uint8_t* cleared, uint32_t* after) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_pre[ENUM_BOARDS][PRE_WORDS];
+    __shared__ __attribute__((aligned(16))) uint32_t s_shapes[SHAPE_WORDS];
+    const int tid = threadIdx.x, b = tid / 40, j = tid - b * 40;
+    const int i = blockIdx.x * ENUM_BOARDS + b;                  // board of this lane
+    const bool live = i < n;
+    uint32_t* pre = s_pre[b];
+    const uint32_t floor_bits = ~0u << H;
+    if (tid < SHAPE_WORDS) s_shapes[tid] = d_shape_table.s[tid];
+    uint32_t mine = 0;
+    if (live && j <= NCOL) {
+        const Ref br = board_ref(geo, safe_player(player, i, P), safe_slot(idx, i, (int)geo.n_games));
+        mine = word_at(br, j < NCOL ? W_COL0 + j : W_PIECE);
+        pre[j < NCOL ? PRE_COL + j : PRE_PIECE] = mine;
+    }
+    if (j == 11) { pre[PRE_BAND] = 0xFFu; pre[PRE_BAND + 1] = 0xFFFF0000u; }
+    if (j >= 12 && j < 16) pre[PRE_STRIP + (j - 12)] = 0u;
+    __syncthreads();
+    if (live) {
+        if (j < NCOL) {
+            int word;
+            const uint32_t bits = pre_band_bits(mine, floor_bits, j, word);
+            atomicOr(&pre[PRE_BAND + word], bits);
+            ((uint8_t*)(pre + PRE_STRIP))[j + 2] = (uint8_t)pre_depth(mine, floor_bits);
+        } else if (j < 21)
+            pre[PRE_PRE + (j - 10)] = pre_and_below(pre + PRE_COL, j - 10);
+        else if (j < 32)
+            pre[PRE_SUF + (j - 21)] = pre_and_from(pre + PRE_COL, j - 21);
+    }
+    __syncthreads();
+    if (!live) return;
+    const size_t t = (size_t)i * 40 + j;
+    const Placement pl = enum_place(pre, s_shapes, H, j / 10, j % 10);
+    valid[t] = (uint8_t)pl.ok;
+    land_y[t] = (int8_t)pl.y;
+    cleared[t] = (uint8_t)pl.cleared;
+    if (after) {
+        const size_t lanes = (size_t)n * 40;
+        for (int c = 0; c < NCOL; c++) {
+            const uint32_t v = enum_after_col(pre, pl, c);
+            if (PLANAR) __builtin_nontemporal_store(v, &after[(size_t)c * lanes + t]);
+            else __builtin_nontemporal_store(v, &after[t * NCOL + c]);
+        }
+    }
 }
 
 template <int P>
@@ -1128,6 +1174,9 @@ int tetris_set_dead(tetris_batch* b, const int32_t* idx, int n, const uint8_t* d
     return finish_call(b);
 }
 
+int tetris_enumerate_drops_dev_ex(tetris_batch* b, const int32_t* d_idx, int n, const uint8_t* d_player, uint8_t* d_valid,
+                                  int8_t* d_land_y, uint8_t* d_cleared, uint32_t* d_after, int flags);
+
 int tetris_enumerate_drops(tetris_batch* b, const int32_t* idx, int n, const uint8_t* player, uint8_t* valid, int8_t* land_y,
                            uint8_t* cleared, uint32_t* after) {
     int rc = check_batch(b);
@@ -1149,14 +1198,8 @@ int tetris_enumerate_drops(tetris_batch* b, const int32_t* idx, int n, const uin
     if ((rc = b->s_out2.ensure(lanes + 4))) return rc;
     if (after && (rc = b->s_big.ensure(lanes * NCOL * 4 + 16))) return rc;
     uint32_t* d_after = after ? (uint32_t*)b->s_big.d : nullptr;
-    dim3 grid((unsigned)((lanes + 255) / 256)), block(256);
-    if (b->P == 1)
-        hipLaunchKernelGGL(k_enumerate<1>, grid, block, 0, b->stream, geo_of_batch(b), n, d_idx, d_player, b->H,
-                           (uint8_t*)b->s_out0.d, (int8_t*)b->s_out1.d, (uint8_t*)b->s_out2.d, d_after);
-    else
-        hipLaunchKernelGGL(k_enumerate<2>, grid, block, 0, b->stream, geo_of_batch(b), n, d_idx, d_player, b->H,
-                           (uint8_t*)b->s_out0.d, (int8_t*)b->s_out1.d, (uint8_t*)b->s_out2.d, d_after);
-    HIP_TRY(hipGetLastError());
+    if ((rc = tetris_enumerate_drops_dev_ex(b, d_idx, n, d_player, (uint8_t*)b->s_out0.d, (int8_t*)b->s_out1.d, (uint8_t*)b->s_out2.d,
+                                            d_after, 0))) return rc;
     HIP_TRY(hipMemcpyAsync(b->s_out0.h, b->s_out0.d, lanes, hipMemcpyDeviceToHost, b->stream));
     HIP_TRY(hipMemcpyAsync(b->s_out1.h, b->s_out1.d, lanes, hipMemcpyDeviceToHost, b->stream));
     HIP_TRY(hipMemcpyAsync(b->s_out2.h, b->s_out2.d, lanes, hipMemcpyDeviceToHost, b->stream));
@@ -1167,23 +1210,29 @@ int tetris_enumerate_drops(tetris_batch* b, const int32_t* idx, int n, const uin
     return TETRIS_OK;
 }
 
-int tetris_enumerate_drops_dev(tetris_batch* b, const int32_t* d_idx, int n, const uint8_t* d_player, uint8_t* d_valid,
-                               int8_t* d_land_y, uint8_t* d_cleared, uint32_t* d_after) {
+int tetris_enumerate_drops_dev_ex(tetris_batch* b, const int32_t* d_idx, int n, const uint8_t* d_player, uint8_t* d_valid,
+                                  int8_t* d_land_y, uint8_t* d_cleared, uint32_t* d_after, int flags) {
     int rc = check_batch(b);
     if (rc) return rc;
     if (!d_valid || !d_land_y || !d_cleared) return fail(TETRIS_E_ARG, "valid/land_y/cleared are NULL");
     if (n < 0 || (!d_idx && n > b->N)) return fail(TETRIS_E_ARG, "n out of range");
+    if (flags & ~TETRIS_ENUM_AFTER_PLANAR) return fail(TETRIS_E_ARG, "unknown flag");
     if (n == 0) return TETRIS_OK;
-    const size_t lanes = (size_t)n * 40;
-    dim3 grid((unsigned)((lanes + 255) / 256)), block(256);
-    if (b->P == 1)
-        hipLaunchKernelGGL(k_enumerate<1>, grid, block, 0, b->stream, geo_of_batch(b), n, d_idx, d_player, b->H, d_valid, d_land_y,
-                           d_cleared, d_after);
-    else
-        hipLaunchKernelGGL(k_enumerate<2>, grid, block, 0, b->stream, geo_of_batch(b), n, d_idx, d_player, b->H, d_valid, d_land_y,
-                           d_cleared, d_after);
+    dim3 grid((unsigned)((n + ENUM_BOARDS - 1) / ENUM_BOARDS)), block(ENUM_BLOCK);
+    const Geo geo = geo_of_batch(b);
+    const bool planar = (flags & TETRIS_ENUM_AFTER_PLANAR) != 0;
+#define LAUNCH_ENUM(PP, PL) hipLaunchKernelGGL((k_enumerate<PP, PL>), grid, block, 0, b->stream, geo, n, d_idx, d_player, b->H, d_valid, \
+                                               d_land_y, d_cleared, d_after)
+    if (b->P == 1) { if (planar) LAUNCH_ENUM(1, true); else LAUNCH_ENUM(1, false); }
+    else { if (planar) LAUNCH_ENUM(2, true); else LAUNCH_ENUM(2, false); }
+#undef LAUNCH_ENUM
     HIP_TRY(hipGetLastError());
     return TETRIS_OK;
+}
+
+int tetris_enumerate_drops_dev(tetris_batch* b, const int32_t* d_idx, int n, const uint8_t* d_player, uint8_t* d_valid,
+                               int8_t* d_land_y, uint8_t* d_cleared, uint32_t* d_after) {
+    return tetris_enumerate_drops_dev_ex(b, d_idx, n, d_player, d_valid, d_land_y, d_cleared, d_after, 0);
 }
 
 int tetris_timer_start(tetris_batch* b) {

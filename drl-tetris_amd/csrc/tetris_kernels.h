@@ -387,38 +387,156 @@ TE_HD int observe_board(const Geo& geo, size_t slot, int p, int H, uint8_t* cell
     return (int)(w & 7);
 }
 
-// TestField.cpp:64-125 (drop placements): lane t = (game i, rotation r, column index xi)
-template <int P>
-// `after_row`: row of `after` ([row][10] words) this placement writes
-TE_HD void enumerate_body(const Geo& geo, size_t t, const int32_t* idx, const uint8_t* player, int H,
-                          const uint32_t* shapes, uint8_t* valid, int8_t* land_y, uint8_t* cleared, uint32_t* after, size_t after_row) {
-    const int i = (int)(t / 40), j = (int)(t % 40), r = j / 10, xi = j % 10;
-    const size_t slot = safe_slot(idx, i, (int)geo.n_games);
-    const int p = safe_player(player, i, P);
+// ---------------------------------------------------------------- drop enumeration (BASELINE config 4)
+// TestField.cpp:64-125 (drop placements) + simulate_actions(finalize=False) (tetris_environment.py:87-100): 40 placements
+// (rotation r = 0..3, column index xi = 0..9, x = xi - 1) per board.  Everything that is the same for the 40 placements
+// of a board is computed ONCE per board into a `BoardPre` (on the GPU: cooperatively by the board's 40 lanes, in LDS):
+//   col[10]   the board's columns          band     the collision window of row 0 (see tetris_engine.h)
+//   strip     per-column free depth from row 0 as bytes [wall wall d0..d9 wall wall wall wall] (hard drop, see drop_distance_bytes)
+//   pre/suf   pre[i] = AND of columns < i, suf[i] = AND of columns >= i: the full-row mask of a stamped board is
+//             pre[x] & suf[x + 4] & (the four columns under the piece | its cells) — no pass over all ten columns
+// A placement lane then needs ~10 LDS reads and no loop over the board.
+constexpr int PRE_COL = 0, PRE_PIECE = 10, PRE_BAND = 11, PRE_STRIP = 13, PRE_PRE = 17, PRE_SUF = 28, PRE_WORDS = 40;
+constexpr int ENUM_BOARDS = 8, ENUM_BLOCK = ENUM_BOARDS * 40;      // boards / threads per workgroup of k_enumerate
+
+// element functions of the per-board precompute (lane j of a board calls the ones its index selects)
+TE_HD uint32_t pre_band_bits(uint32_t col, uint32_t floor_bits, int c, int& word) {      // nibble c+2 of the 64-bit band
+    const uint32_t nib = (col | floor_bits) & 0xFu;
+    word = c >= 6;
+    return nib << (c >= 6 ? 4 * (c - 6) : 4 * c + 8);
+}
+TE_HD uint32_t pre_depth(uint32_t col, uint32_t floor_bits) { return (uint32_t)ctz32(col | floor_bits); }   // H <= 31: never zero
+TE_HD uint32_t pre_and_below(const uint32_t* col, int i) {      // AND of columns < i (i = 0..10)
+    uint32_t v = ~0u;
+    for (int c = 0; c < NCOL; c++) v &= (c < i) ? col[c] : ~0u;
+    return v;
+}
+TE_HD uint32_t pre_and_from(const uint32_t* col, int i) {       // AND of columns >= i (i = 0..10)
+    uint32_t v = ~0u;
+    for (int c = 0; c < NCOL; c++) v &= (c >= i) ? col[c] : ~0u;
+    return v;
+}
+
+// serial form of the precompute (CPU harness; the GPU kernel spreads the same element functions over a board's lanes)
+TE_HD void enum_prepare(const Geo& geo, size_t slot, int p, int H, uint32_t* pre) {
     const Ref br = board_ref(geo, p, slot);
-    Player q;
-    for (int c = 0; c < NCOL; c++) q.col[c] = word_at(br, W_COL0 + c);
-    const uint32_t w = word_at(br, W_PIECE);
+    const uint32_t floor_bits = ~0u << H;
+    for (int c = 0; c < NCOL; c++) pre[PRE_COL + c] = word_at(br, W_COL0 + c);
+    pre[PRE_PIECE] = word_at(br, W_PIECE);
+    pre[PRE_BAND] = 0xFFu; pre[PRE_BAND + 1] = 0xFFFF0000u;
+    for (int k = 0; k < 4; k++) pre[PRE_STRIP + k] = 0;
+    for (int c = 0; c < NCOL; c++) {
+        int word;
+        const uint32_t bits = pre_band_bits(pre[PRE_COL + c], floor_bits, c, word);
+        pre[PRE_BAND + word] |= bits;
+        pre[PRE_STRIP + ((c + 2) >> 2)] |= pre_depth(pre[PRE_COL + c], floor_bits) << (8 * ((c + 2) & 3));
+    }
+    for (int i = 0; i <= NCOL; i++) { pre[PRE_PRE + i] = pre_and_below(pre + PRE_COL, i); pre[PRE_SUF + i] = pre_and_from(pre + PRE_COL, i); }
+}
+
+struct Placement { int ok, y, cleared; uint32_t cells[4]; int x; };     // cells[k] = the piece's squares in board column x + k
+
+// one placement against a prepared board (`pre` = its BoardPre; LDS on the GPU)
+TE_HD Placement enum_place(const uint32_t* pre, const uint32_t* shapes, int H, int r, int xi) {
+    Placement out;
+    const uint32_t floor_bits = ~0u << H;
+    const uint32_t w = pre[PRE_PIECE];
     const int kind = w & 7, cur_rot = (w >> 3) & 3;
-    Ctx cx;
-    cx.shapes = shapes; cx.H = H; cx.floor_bits = ~0u << H; cx.tint = false; cx.queue = true;
     const int n_rot = kind == 6 ? 1 : (kind == 4 || kind == 2 || kind == 3) ? 2 : 4;     // TestField.cpp:71-109
     const int rot = kind == 6 ? cur_rot : r;                                               // O is used as it stands
-    const uint32_t shape = shapes[((kind & 7) << 2) | rot];
-    q.kind = kind; q.rot = rot; q.x = xi - 1; q.y = 0;
-    bool ok = kind <= 6 && r < n_rot && q.x <= NCOL - 2 && fits_at(cx, q, shape, q.x, 0);
-    int y = 0, gone = 0;
-    if (ok) {
-        y = drop_distance_bytes(cx, q, shape, shapes[32 + (((kind & 7) << 2) | rot)]);
-        q.y = y;
-        stamp(cx, q, shape);
+    const uint32_t shape = shapes[((kind & 7) << 2) | rot], nibs = shape & 0xFFFFu;
+    const int x = xi - 1;
+    const unsigned xs = (unsigned)(x + 2);                                                 // 1..10
+    const uint64_t band = ((uint64_t)pre[PRE_BAND + 1] << 32) | pre[PRE_BAND];
+    out.x = x;
+    out.ok = kind <= 6 && r < n_rot && x <= NCOL - 2 && (((uint64_t)nibs << (4 * xs)) & band) == 0;   // gameField.cpp:10-20 at (x, 0)
+    out.y = 0; out.cleared = 0;
+    for (int k = 0; k < 4; k++) out.cells[k] = 0;
+    if (!out.ok) return out;
+    // hard drop (gameField.cpp:49-53): the four depths under the piece + the shape's drop word, byte minimum
+    const uint32_t lo = pre[PRE_STRIP + (xs >> 2)], hi = (xs >> 2) < 3 ? pre[PRE_STRIP + (xs >> 2) + 1] : 0u;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t under = __builtin_amdgcn_alignbyte(hi, lo, xs & 3u);
+#else
+    const uint32_t under = (uint32_t)((((uint64_t)hi << 32) | lo) >> (8 * (xs & 3u)));
+#endif
+    const uint32_t sum = under + shapes[32 + (((kind & 7) << 2) | rot)];
+    const uint32_t b0 = sum & 0xFFu, b1 = (sum >> 8) & 0xFFu, b2 = (sum >> 16) & 0xFFu, b3 = sum >> 24;
+    const uint32_t m01 = b0 < b1 ? b0 : b1, m23 = b2 < b3 ? b2 : b3;
+    uint32_t m = m01 < m23 ? m01 : m23;
+    int y;
+    if (m - 0x40u > 0x3Eu) {          // an obstacle above a piece column's top cell inside the 4x4 box: exact closed form per column
+        int dist = 64;
+        for (int gx = 0; gx < 4; gx++) {
+            const uint32_t nib = (nibs >> (4 * gx)) & 0xFu;
+            const int c = x + gx;
+            if (nib && c >= 0 && c < NCOL) {
+                const int top = ctz32(nib), bottom = 31 - clz32(nib);
+                const uint32_t below = (pre[PRE_COL + c] | floor_bits) >> (top + 1);
+                const int first = below ? ctz32(below) + top + 1 : 32;
+                dist = imin(dist, imax(0, first - bottom - 1));
+            }
+        }
+        y = dist == 64 ? 0 : dist;
+    } else
+        y = (int)(m - 0x40u);
+    out.y = y;
+    // stamp (gameField.cpp:105-110) and the rows a finalize would clear (gameField.cpp:120-145)
+    const int lo_c = imax(0, imin(NCOL, x)), hi_c = imax(0, imin(NCOL, x + 4));
+    uint32_t full = pre[PRE_PRE + lo_c] & pre[PRE_SUF + hi_c];
+    for (int k = 0; k < 4; k++) {
+        const int c = x + k;
+        const uint32_t cells = ((nibs >> (4 * k)) & 0xFu) << y;
+        const bool inside = c >= 0 && c < NCOL;
+        out.cells[k] = inside ? cells : 0u;
+        if (inside) full &= pre[PRE_COL + c] | cells;
     }
-    valid[t] = ok ? 1 : 0;
-    land_y[t] = (int8_t)y;
+    const uint32_t range = (~0u << y) & ~floor_bits;
+    if (full & ~range & ~floor_bits) {
+        // a full row ABOVE the piece (unreachable by play; only a crafted restore could hold one): the reference re-scans rows
+        // that shift into range, so count exactly like clear_rows
+        uint32_t colv[NCOL];
+        for (int c = 0; c < NCOL; c++) colv[c] = pre[PRE_COL + c];
+        for (int k = 0; k < 4; k++) { const int c = x + k; if (c >= 0 && c < NCOL) for (int cc = 0; cc < NCOL; cc++) if (cc == c) colv[cc] |= out.cells[k]; }
+        int cleared = 0;
+        for (;;) {
+            uint32_t f = range;
+            for (int c = 0; c < NCOL; c++) f &= colv[c];
+            if (!f) break;
+            const int rr = 31 - clz32(f);
+            const uint32_t above = (1u << rr) - 1u, keep = ~((above << 1) | 1u);
+            for (int c = 0; c < NCOL; c++) colv[c] = (colv[c] & keep) | ((colv[c] & above) << 1);
+            cleared++;
+        }
+        out.cleared = cleared;
+    } else
+        out.cleared = __builtin_popcount(full & range);
+    return out;
+}
+
+// column c of the stamped board of a placement
+TE_HD uint32_t enum_after_col(const uint32_t* pre, const Placement& pl, int c) {
+    const int k = c - pl.x;
+    uint32_t cells = 0;
+    cells = k == 0 ? pl.cells[0] : cells; cells = k == 1 ? pl.cells[1] : cells;
+    cells = k == 2 ? pl.cells[2] : cells; cells = k == 3 ? pl.cells[3] : cells;
+    return pre[PRE_COL + c] | cells;
+}
+
+// serial driver of one placement (CPU harness): lane t = (game i, rotation r, column index xi)
+// `planar`: after[c][lanes] instead of after[lane][c]
+template <int P>
+TE_HD void enumerate_body(const Geo& geo, size_t t, const int32_t* idx, const uint8_t* player, int H,
+                          const uint32_t* shapes, uint8_t* valid, int8_t* land_y, uint8_t* cleared, uint32_t* after, size_t lanes, bool planar) {
+    const int i = (int)(t / 40), j = (int)(t % 40), r = j / 10, xi = j % 10;
+    uint32_t pre[PRE_WORDS];
+    enum_prepare(geo, safe_slot(idx, i, (int)geo.n_games), safe_player(player, i, P), H, pre);
+    const Placement pl = enum_place(pre, shapes, H, r, xi);
+    valid[t] = (uint8_t)pl.ok;
+    land_y[t] = (int8_t)pl.y;
+    cleared[t] = (uint8_t)pl.cleared;
     if (after)
-        for (int c = 0; c < NCOL; c++) after[after_row * NCOL + c] = q.col[c];
-    if (ok) gone = clear_rows(cx, q);
-    cleared[t] = (uint8_t)gone;
+        for (int c = 0; c < NCOL; c++) after[planar ? (size_t)c * lanes + t : t * NCOL + c] = enum_after_col(pre, pl, c);
 }
 
 // PythonHandle.cpp:190 get_actions -> TestField.cpp:64-111 getMask(2): lane t = (game i, rotation r, column xi);

@@ -165,6 +165,12 @@ int tetris_enumerate_drops(tetris_batch *b, const int32_t *idx, int n, const uin
 /* same with device pointers (d_idx / d_player may be NULL), asynchronous on the batch's stream                        */
 int tetris_enumerate_drops_dev(tetris_batch *b, const int32_t *d_idx, int n, const uint8_t *d_player,
                                uint8_t *d_valid, int8_t *d_land_y, uint8_t *d_cleared, uint32_t *d_after);
+/* same with flags.  TETRIS_ENUM_AFTER_PLANAR: d_after is [10][n*40] — column c of placement t at d_after[c * n*40 + t],
+ * t = (game * 4 + r) * 10 + xi — instead of [n*40][10]: every store of a wavefront is then 256 contiguous bytes, and a
+ * consumer that feeds the afterstates to a network reads one column plane at a time.                                 */
+#define TETRIS_ENUM_AFTER_PLANAR 1
+int tetris_enumerate_drops_dev_ex(tetris_batch *b, const int32_t *d_idx, int n, const uint8_t *d_player,
+                                  uint8_t *d_valid, int8_t *d_land_y, uint8_t *d_cleared, uint32_t *d_after, int flags);
 
 /* replaces: PythonHandle.get_actions(player); masks[player].action (PythonHandle.cpp:190, TestField.cpp:64-415):
  * the reference's exact ordered key lists of the "place_block" action type — every (x, rotation) drop plus the

@@ -70,16 +70,20 @@ dv = dict(dtype=torch.uint8, device="cuda")
 valid, land, cleared = torch.zeros(n * 40, **dv), torch.zeros(n * 40, dtype=torch.int8, device="cuda"), torch.zeros(n * 40, **dv)
 after = torch.zeros(n * 400, dtype=torch.int32, device="cuda")
 torch.cuda.synchronize()
-for _ in range(5):
-    b._check(b.lib.tetris_enumerate_drops_dev(b._h, None, n, None, ptr(valid), ptr(land), ptr(cleared), ptr(after)))
-b.timer_start()
-reps = 200
-for _ in range(reps):
-    b._check(b.lib.tetris_enumerate_drops_dev(b._h, None, n, None, ptr(valid), ptr(land), ptr(cleared), ptr(after)))
-us = b.timer_stop() * 1e3 / reps
-bytes_per_call = n * 44 + n * 40 * 43
-out["C4_enumerate_drops_16k_device"] = {"us_per_call": us, "afterstates_per_s": n * 40 / (us * 1e-6), "algorithmic_bytes": bytes_per_call,
-                                        "GBps": bytes_per_call / (us * 1e-6) / 1e9, "frac_of_8TBps": bytes_per_call / (us * 1e-6) / 8e12}
+bytes_per_call = n * 44 + n * 40 * 43          # SURVEY: 44 B per board in, 43 B per placement out (valid, land_y, cleared, 10 columns)
+for name, with_after, planar in (("rows", True, False), ("planar", True, True), ("no_after", False, False)):
+    a_ptr = ptr(after) if with_after else None
+    for _ in range(5):
+        b.enumerate_drops_dev(n, ptr(valid), ptr(land), ptr(cleared), a_ptr, planar=planar)
+    b.timer_start()
+    reps = 200
+    for _ in range(reps):
+        b.enumerate_drops_dev(n, ptr(valid), ptr(land), ptr(cleared), a_ptr, planar=planar)
+    us = b.timer_stop() * 1e3 / reps
+    nbytes = bytes_per_call if with_after else n * 44 + n * 40 * 3
+    out["C4_enumerate_drops_16k_device" + ("" if name == "rows" else "_" + name)] = {
+        "us_per_call": us, "afterstates_per_s": n * 40 / (us * 1e-6), "algorithmic_bytes": nbytes,
+        "GBps": nbytes / (us * 1e-6) / 1e9, "frac_of_8TBps": nbytes / (us * 1e-6) / 8e12}
 b.close()
 
 b = pkg.TetrisBatch(65536, 2, 20, 10, seeds=np.arange(65536))
@@ -98,8 +102,9 @@ out["observe_packed_64k_2p_device"] = {"us_per_call": us, "player_boards_per_s":
                                        "GBps": bytes_per_call / (us * 1e-6) / 1e9, "frac_of_8TBps": bytes_per_call / (us * 1e-6) / 8e12}
 b.close()
 
-# the NN-policy shape: actions arrive as device arrays, outputs stay on the device (tetris_step_rt_dev), no resets inside the
-# timed region (boards that end stay round_over, as between perform_action and reset in the reference's loop)
+# the NN-policy shape: actions arrive as device arrays, outputs stay on the device (tetris_step_rt_dev_ex with device-side
+# auto-reset): STEADY STATE — 64 warm-up steps, then 2048 timed steps with the resets of finished games inside the launches
+# (about one game in twenty ends per step), no host synchronisation anywhere in the loop
 for P in (1, 2):
     b = pkg.TetrisBatch(65536, P, 20, 10, seeds=np.arange(65536))
     n = 65536
@@ -109,22 +114,20 @@ for P in (1, 2):
     trans = torch.randint(0, 10, (K, n), generator=gen, device="cuda", dtype=torch.uint8)
     who = torch.randint(0, P, (K, n), generator=gen, device="cuda", dtype=torch.uint8)
     done, lines, dead = torch.zeros(n, **dv), torch.zeros(P * n, **dv), torch.zeros(P * n, **dv)
+    finished = torch.zeros(n, dtype=torch.int32, device="cuda")
     torch.cuda.synchronize()
-    # windows of 4 and of 12 launches on freshly reset boards; the slope (t12 - t4) / 8 is the cost of one launch without the
-    # event pair and the pipeline fill of a short window (steps 4..11 of an episode: hardly any game has ended yet)
-    t = {4: 0.0, 12: 0.0}
-    reps = 40
-    for rep in range(reps):
-        for w in (4, 12):
-            b.reset(None, seeds=((12345 + 7919 * np.arange(n) + 104729 * rep) & 0xFFFF).astype(np.uint16).view(np.int16))
-            b.timer_start()
-            for k in range(w):
-                j = (rep * 12 + k) % K
-                b._check(b.lib.tetris_step_rt_dev(b._h, ptr(rots[j]), ptr(trans[j]), ptr(who[j]), 400, ptr(done), ptr(lines), ptr(dead)))
-            t[w] += b.timer_stop() * 1e3
-    us = (t[12] - t[4]) / reps / 8
+    for k in range(64):
+        b.step_rt_dev(ptr(rots[k % K]), ptr(trans[k % K]), ptr(who[k % K]), ptr(done), ptr(lines), ptr(dead), auto_reset=True)
+    b.sync()
+    steps = 2048
+    b.timer_start()
+    for k in range(steps):
+        b.step_rt_dev(ptr(rots[k % K]), ptr(trans[k % K]), ptr(who[k % K]), ptr(done), ptr(lines), ptr(dead), auto_reset=True)
+    us = b.timer_stop() * 1e3 / steps
+    b.sync()
     algo = (389 if P == 1 else 774) * n
-    out[f"step_rt_dev_{P}p_64k_device"] = {"us_per_call": us, "env_steps_per_s": n / (us * 1e-6), "algorithmic_bytes": algo,
-                                            "GBps": algo / (us * 1e-6) / 1e9, "frac_of_8TBps": algo / (us * 1e-6) / 8e12}
+    out[f"step_rt_dev_auto_reset_{P}p_64k_steady_state"] = {
+        "us_per_call": us, "env_steps_per_s": n / (us * 1e-6), "algorithmic_bytes": algo, "GBps": algo / (us * 1e-6) / 1e9,
+        "frac_of_8TBps": algo / (us * 1e-6) / 8e12, "steps_timed": steps, "games_finished_in_last_step": int(done.sum().item())}
     b.close()
 print(json.dumps(out))

@@ -349,18 +349,21 @@ int tetris_set_dead(tetris_batch* b, const int32_t* idx, int n, const uint8_t* d
     return TETRIS_OK;
 }
 
-int tetris_enumerate_drops(tetris_batch* b, const int32_t* idx, int n, const uint8_t* player, uint8_t* valid, int8_t* land_y,
-                           uint8_t* cleared, uint32_t* after) {
+int tetris_enumerate_drops_dev_ex(tetris_batch* b, const int32_t* idx, int n, const uint8_t* player, uint8_t* valid, int8_t* land_y,
+                                  uint8_t* cleared, uint32_t* after, int flags) {
     int rc = check_idx(b, idx, n); if (rc) return rc;
-    for (size_t t = 0; t < (size_t)n * 40; t++) {
-        if (b->P == 1) enumerate_body<1>(geo_of_batch(b), t, idx, player, b->H, SHAPES.s, valid, land_y, cleared, after, t);
-        else enumerate_body<2>(geo_of_batch(b), t, idx, player, b->H, SHAPES.s, valid, land_y, cleared, after, t);
+    if (flags & ~TETRIS_ENUM_AFTER_PLANAR) return fail(TETRIS_E_ARG, "unknown flag");
+    const size_t lanes = (size_t)n * 40;
+    for (size_t t = 0; t < lanes; t++) {
+        if (b->P == 1) enumerate_body<1>(geo_of_batch(b), t, idx, player, b->H, SHAPES.s, valid, land_y, cleared, after, lanes, flags & TETRIS_ENUM_AFTER_PLANAR);
+        else enumerate_body<2>(geo_of_batch(b), t, idx, player, b->H, SHAPES.s, valid, land_y, cleared, after, lanes, flags & TETRIS_ENUM_AFTER_PLANAR);
     }
     return TETRIS_OK;
 }
-
+int tetris_enumerate_drops(tetris_batch* b, const int32_t* idx, int n, const uint8_t* player, uint8_t* valid, int8_t* land_y,
+                           uint8_t* cleared, uint32_t* after) { return tetris_enumerate_drops_dev_ex(b, idx, n, player, valid, land_y, cleared, after, 0); }
 int tetris_enumerate_drops_dev(tetris_batch* b, const int32_t* idx, int n, const uint8_t* player, uint8_t* valid, int8_t* land_y,
-                               uint8_t* cleared, uint32_t* after) { return tetris_enumerate_drops(b, idx, n, player, valid, land_y, cleared, after); }
+                               uint8_t* cleared, uint32_t* after) { return tetris_enumerate_drops_dev_ex(b, idx, n, player, valid, land_y, cleared, after, 0); }
 int tetris_timer_start(tetris_batch*) { return TETRIS_OK; }
 int tetris_timer_stop(tetris_batch*, float* ms) { if (ms) *ms = 0.0f; return TETRIS_OK; }
 

@@ -358,6 +358,21 @@ def test_enumerate_drops_matches_oracle(kind):
     v1, y1, c1, _ = eng.enumerate_drops(idx=sub, player=1, columns=False)
     v2, y2, c2, _ = ref.enumerate_drops(idx=sub, player=1, cells=False)
     assert np.array_equal(v1, v2) and np.array_equal(y1, y2) and np.array_equal(c1, c2)
+    # device-pointer form, both `after` layouts (rows [n*40][10] and column planes [10][n*40]), with a ragged last workgroup
+    D = _DevArrays(kind)
+    m = n - 3
+    player = rng.integers(0, 2, m).astype(np.uint8)
+    want = eng.enumerate_drops(idx=np.arange(m, dtype=np.int32), player=player)
+    for planar in (False, True):
+        v_d, y_d, c_d = D.put(np.zeros(m * 40, np.uint8)), D.put(np.zeros(m * 40, np.int8)), D.put(np.zeros(m * 40, np.uint8))
+        a_d, p_d = D.put(np.zeros(m * 400, np.uint32).view(np.int32)), D.put(player)
+        eng.enumerate_drops_dev(m, D.ptr(v_d), D.ptr(y_d), D.ptr(c_d), D.ptr(a_d), player=D.ptr(p_d), planar=planar)
+        eng.sync()
+        assert np.array_equal(D.get(v_d).reshape(m, 4, 10), want[0]) and np.array_equal(D.get(y_d).reshape(m, 4, 10), want[1])
+        assert np.array_equal(D.get(c_d).reshape(m, 4, 10), want[2])
+        a = D.get(a_d).view(np.uint32)
+        a = a.reshape(10, m, 4, 10).transpose(1, 2, 3, 0) if planar else a.reshape(m, 4, 10, 10)
+        assert np.array_equal(a, want[3]), planar
 
 
 @pytest.mark.parametrize("kind", engines.ENGINE_PARAMS)
