@@ -53,6 +53,7 @@ _SIGNATURES = {
     "tetris_create_ex": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
     "tetris_destroy": (C.c_int, [C.c_void_p]),
     "tetris_sync": (C.c_int, [C.c_void_p]),
+    "tetris_take_errors": (C.c_int, [C.c_void_p, C.c_void_p]),
     "tetris_set_game_offset": (C.c_int, [C.c_void_p, C.c_uint64]),
     "tetris_reset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "tetris_make_actions": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
@@ -300,7 +301,7 @@ class TetrisBatch:
 
     def enumerate_drops_dev(self, n, valid, land_y, cleared, after=None, idx=None, player=None, planar=False):
         """tetris_enumerate_drops_dev_ex: raw DEVICE addresses (int / c_void_p) or None; only enqueues.
-        planar: `after` is [10][n*40] (one column plane after the other) instead of [n*40][10]."""
+        planar: rotation-major outputs — valid / land_y / cleared [4][n][10], after [10][4][n][10]."""
         self._check(self.lib.tetris_enumerate_drops_dev_ex(self._h, idx, int(n), player, valid, land_y, cleared, after, 1 if planar else 0))
 
     def get_actions(self, idx=None, player=None, max_lists=64, max_keys=48):
@@ -362,6 +363,13 @@ class TetrisBatch:
 
     def sync(self):
         self._check(self.lib.tetris_sync(self._h))
+
+    def take_errors(self):
+        """-> TETRIS_ERR_* bits (1 = a garbage queue overflowed, 2 = an episode outran the RNG tables) of games that were ended by
+        a capacity error since the last call; which games: observe()[0]["fifo_overflow"]."""
+        bits = C.c_uint32(0)
+        self._check(self.lib.tetris_take_errors(self._h, C.byref(bits)))
+        return int(bits.value)
 
     @property
     def table_chunks(self):

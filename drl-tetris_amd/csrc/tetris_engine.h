@@ -86,11 +86,25 @@ extern unsigned long long te_path_count[PC_NCOUNTERS];
 // State word `word_off` (in words, uniform across the wave) of the board at byte offset `o` (per lane, < 4 GiB) of a
 // uniform base: on the GPU the base + word offset stay in SGPRs and the lane offset is the 32-bit VGPR offset of the
 // global_load/store, so the ~60 state accesses of a step need no per-lane 64-bit address arithmetic.
-TE_HD uint32_t ldw(const uint32_t* base, uint32_t o, size_t word_off) {
-    return ld_stream((const uint32_t*)((const char*)(base + word_off) + o));
+// Memory mode of a state access.  MEM_STREAM: non-temporal (the default: a state word is touched once per launch).
+// MEM_AGENT: agent-scope (`sc1`) — the word is handed from one launch to the next WHILE both are running (chained launches,
+// tetris_hip.hip): the store is written through to memory and the load bypasses the non-coherent per-XCD L2
+// (MI355X_MICROARCH.md, inter-workgroup visibility: every store and every load of the handed-off bytes must be `sc1`).
+enum MemMode : int { MEM_STREAM = 0, MEM_AGENT = 1 };
+#if defined(__HIP_DEVICE_COMPILE__)
+TE_HD uint32_t ld_agent(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+TE_HD void st_agent(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#else
+TE_HD uint32_t ld_agent(const uint32_t* p) { return *p; }
+TE_HD void st_agent(uint32_t* p, uint32_t v) { *p = v; }
+#endif
+TE_HD uint32_t ldw(const uint32_t* base, uint32_t o, size_t word_off, int mem = MEM_STREAM) {
+    const uint32_t* p = (const uint32_t*)((const char*)(base + word_off) + o);
+    return mem == MEM_AGENT ? ld_agent(p) : ld_stream(p);
 }
-TE_HD void stw(uint32_t* base, uint32_t o, size_t word_off, uint32_t v) {
-    st_stream((uint32_t*)((char*)(base + word_off) + o), v);
+TE_HD void stw(uint32_t* base, uint32_t o, size_t word_off, uint32_t v, int mem = MEM_STREAM) {
+    uint32_t* p = (uint32_t*)((char*)(base + word_off) + o);
+    if (mem == MEM_AGENT) st_agent(p, v); else st_stream(p, v);
 }
 #if defined(__HIP_DEVICE_COMPILE__)
 TE_HD void add_word(uint32_t* p, uint32_t v) { (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -171,6 +185,12 @@ struct Ctx {
     bool queue;                      // garbage queue / incoming lines can exist (false in 1-player kernels: nothing ever sends)
 };
 
+// Capacity errors are confined to the game they happen in (the reference's queue and generators are unbounded: Garbage.h:27,
+// randomizer.h:44-50): the board gets an error bit (W_MISC[28:30), tetris_record.fifo_overflow), the game's round is over
+// (`done`), every other game of the batch goes on.  A reset clears the bits.
+constexpr int ERR_FIFO = 1;      // more than FIFO_CAP garbage packets were pending: one was dropped
+constexpr int ERR_STREAM = 2;    // the episode ran past the RNG tables (MAX_CHUNKS * 624 draws): the dealt pieces are wrong
+
 // ---------------------------------------------------------------- one player-board in registers
 struct Raw8 { uint32_t lo, hi; };   // 8 raw RNG-table bytes
 struct Player {
@@ -178,7 +198,8 @@ struct Player {
     uint32_t tint[3][NCOL];          // colour planes (only touched when Ctx::tint)
     int kind, rot, x, y, next;
     int dead, lock_armed, reward;
-    int inc_count, combo_count, line_count, qlen, q_overflow;
+    int inc_count, combo_count, line_count, qlen;
+    int q_overflow;                  // per-board error bits (ERR_*): the game is over, the board's state is not the reference's
     int32_t time_ms, drop_delay, drop_time, speedup_time, lock_time;
     int32_t combo_start, combo_time, min_remaining;
     uint32_t combo_remaining;
@@ -212,113 +233,113 @@ struct Game {
 // ---------------------------------------------------------------- load / store (SoA, coalesced)
 // state[(w * P + p) * n + slot]; game words at gstate[w * n + slot]
 // one player-board: word w of this board lives at s[w * ws]
-TE_HD void load_player(const uint32_t* s, uint32_t o, size_t ws, Player& q, bool tint, bool queue = true) {
-    for (int c = 0; c < NCOL; c++) q.col[c] = ldw(s, o, (size_t)(W_COL0 + c) * ws);
+TE_HD void load_player(const uint32_t* s, uint32_t o, size_t ws, Player& q, bool tint, bool queue = true, int mem = MEM_STREAM) {
+    for (int c = 0; c < NCOL; c++) q.col[c] = ldw(s, o, (size_t)(W_COL0 + c) * ws, mem);
     if (tint)
         for (int k = 0; k < 3; k++)
-            for (int c = 0; c < NCOL; c++) q.tint[k][c] = ldw(s, o, (size_t)(W_TINT0 + 10 * k + c) * ws);
-    uint32_t w = ldw(s, o, (size_t)W_PIECE * ws);
+            for (int c = 0; c < NCOL; c++) q.tint[k][c] = ldw(s, o, (size_t)(W_TINT0 + 10 * k + c) * ws, mem);
+    uint32_t w = ldw(s, o, (size_t)W_PIECE * ws, mem);
     q.kind = w & 7; q.rot = (w >> 3) & 3; q.x = (int)((w >> 5) & 15) - 4; q.y = (w >> 9) & 31;
     q.next = (w >> 14) & 7; q.dead = (w >> 17) & 1; q.lock_armed = (w >> 18) & 1; q.reward = (w >> 19) & 255;
-    w = ldw(s, o, (size_t)W_MISC * ws);
+    w = ldw(s, o, (size_t)W_MISC * ws, mem);
     q.inc_count = w & 255; q.combo_count = (w >> 8) & 255; q.line_count = (w >> 16) & 255;
-    q.qlen = (w >> 24) & 15; q.q_overflow = (w >> 28) & 1;
+    q.qlen = (w >> 24) & 15; q.q_overflow = (w >> 28) & 3;
     if (!queue) { q.inc_count = 0; q.qlen = 0; q.q_overflow = 0; }      // invariants of a game without opponents
-    q.time_ms = (int32_t)ldw(s, o, (size_t)W_TIME * ws);
-    w = ldw(s, o, (size_t)W_DROPCOMBO * ws);
+    q.time_ms = (int32_t)ldw(s, o, (size_t)W_TIME * ws, mem);
+    w = ldw(s, o, (size_t)W_DROPCOMBO * ws, mem);
     q.drop_delay = w & 0xFFFF; q.combo_remaining = w >> 16;
-    q.drop_time = (int32_t)ldw(s, o, (size_t)W_DROP_TIME * ws);
-    q.speedup_time = (int32_t)ldw(s, o, (size_t)W_SPEEDUP_TIME * ws);
-    q.lock_time = (int32_t)ldw(s, o, (size_t)W_LOCK_TIME * ws);
-    q.combo_start = (int32_t)ldw(s, o, (size_t)W_COMBO_START * ws);
-    q.combo_time = (int32_t)ldw(s, o, (size_t)W_COMBO_TIME * ws);
+    q.drop_time = (int32_t)ldw(s, o, (size_t)W_DROP_TIME * ws, mem);
+    q.speedup_time = (int32_t)ldw(s, o, (size_t)W_SPEEDUP_TIME * ws, mem);
+    q.lock_time = (int32_t)ldw(s, o, (size_t)W_LOCK_TIME * ws, mem);
+    q.combo_start = (int32_t)ldw(s, o, (size_t)W_COMBO_START * ws, mem);
+    q.combo_time = (int32_t)ldw(s, o, (size_t)W_COMBO_TIME * ws, mem);
     // nobody can send garbage to a single player: incoming lines, hole draws and the queue timer never leave their
     // reset values (0, 0, 1000), so 1-player kernels neither load nor (for the two zeros) store these words
-    q.incoming = queue ? u2f(ldw(s, o, (size_t)W_INCOMING * ws)) : 0.0f;
-    q.min_remaining = queue ? (int32_t)ldw(s, o, (size_t)W_MIN_REMAINING * ws) : 1000;
-    q.piece_draws = ldw(s, o, (size_t)W_PIECE_DRAWS * ws);
-    q.hole_draws = queue ? ldw(s, o, (size_t)W_HOLE_DRAWS * ws) : 0u;
-    q.pgroup = ldw(s, o, (size_t)W_PIECE_GROUP * ws);
-    w = ldw(s, o, (size_t)W_STATS0 * ws); q.lines_sent = w & 0xFFFF; q.lines_cleared = w >> 16;
-    w = ldw(s, o, (size_t)W_STATS1 * ws); q.lines_blocked = w & 0xFFFF; q.max_combo = w >> 16;
-    w = ldw(s, o, (size_t)W_STATS2 * ws); q.lines_seen = w & 0xFFFF; q.garbage_cleared = w >> 16;
+    q.incoming = queue ? u2f(ldw(s, o, (size_t)W_INCOMING * ws, mem)) : 0.0f;
+    q.min_remaining = queue ? (int32_t)ldw(s, o, (size_t)W_MIN_REMAINING * ws, mem) : 1000;
+    q.piece_draws = ldw(s, o, (size_t)W_PIECE_DRAWS * ws, mem);
+    q.hole_draws = queue ? ldw(s, o, (size_t)W_HOLE_DRAWS * ws, mem) : 0u;
+    q.pgroup = ldw(s, o, (size_t)W_PIECE_GROUP * ws, mem);
+    w = ldw(s, o, (size_t)W_STATS0 * ws, mem); q.lines_sent = w & 0xFFFF; q.lines_cleared = w >> 16;
+    w = ldw(s, o, (size_t)W_STATS1 * ws, mem); q.lines_blocked = w & 0xFFFF; q.max_combo = w >> 16;
+    w = ldw(s, o, (size_t)W_STATS2 * ws, mem); q.lines_seen = w & 0xFFFF; q.garbage_cleared = w >> 16;
     q.q_loaded = queue && q.qlen > 0;
     q.pf_ok = 0; q.pf_raw.lo = 0; q.pf_raw.hi = 0;
     if (queue)
         for (int i = 0; i < FIFO_CAP; i++) { q.qcount[i] = 0; q.qdelay[i] = 0; }
     if (q.q_loaded) {
         for (int i = 0; i < FIFO_CAP / 2; i++) {
-            uint32_t cw = ldw(s, o, (size_t)(W_FIFO_COUNT0 + i) * ws);
+            uint32_t cw = ldw(s, o, (size_t)(W_FIFO_COUNT0 + i) * ws, mem);
             q.qcount[2 * i] = (int16_t)(cw & 0xFFFF);
             q.qcount[2 * i + 1] = (int16_t)(cw >> 16);
         }
-        for (int i = 0; i < FIFO_CAP; i++) q.qdelay[i] = (int32_t)ldw(s, o, (size_t)(W_FIFO_DELAY0 + i) * ws);
+        for (int i = 0; i < FIFO_CAP; i++) q.qdelay[i] = (int32_t)ldw(s, o, (size_t)(W_FIFO_DELAY0 + i) * ws, mem);
     }
 }
 
 // the per-game words; `counters`: also G_STEPS (the built-in rollout)
 template <int P>
-TE_HD void load_game_words(const Ref& gr, Game<P>& g, bool counters = false) {
-    uint32_t meta = ldw(gr.s, gr.o, (size_t)G_META * gr.ws);
+TE_HD void load_game_words(const Ref& gr, Game<P>& g, bool counters = false, int mem = MEM_STREAM) {
+    uint32_t meta = ldw(gr.s, gr.o, (size_t)G_META * gr.ws, mem);
     g.seed16 = meta & 0xFFFFu;
     g.round_over = (meta >> 16) & 1;
     g.last_winner = (int)((meta >> 17) & 0xF) - 1;
     g.flags = (meta >> 21) & 7u;
-    g.episode = ldw(gr.s, gr.o, (size_t)G_EPISODE * gr.ws);
-    g.steps = counters ? ldw(gr.s, gr.o, (size_t)G_STEPS * gr.ws) : 0u;
+    g.episode = ldw(gr.s, gr.o, (size_t)G_EPISODE * gr.ws, mem);
+    g.steps = counters ? ldw(gr.s, gr.o, (size_t)G_STEPS * gr.ws, mem) : 0u;
     g.add_lines = 0; g.add_sent = 0;
     g.status = 0;
 }
 
 template <int P>
-TE_HD void load_game(const Geo& geo_in, size_t slot, Game<P>& g, bool tint = false, bool queue = true, bool counters = false) {
+TE_HD void load_game(const Geo& geo_in, size_t slot, Game<P>& g, bool tint = false, bool queue = true, bool counters = false, int mem = MEM_STREAM) {
     Geo geo = geo_in;
     geo.P = P;                           // compile-time stride factor for the hot loads
-    load_game_words<P>(game_ref(geo, slot), g, counters);
+    load_game_words<P>(game_ref(geo, slot), g, counters, mem);
     TE_UNROLL
     for (int p = 0; p < P; p++) {
         const Ref r = board_ref(geo, p, slot);
-        load_player(r.s, r.o, r.ws, g.pl[p], tint, queue);
+        load_player(r.s, r.o, r.ws, g.pl[p], tint, queue, mem);
     }
 }
 
-TE_HD void store_player(uint32_t* s, uint32_t o, size_t ws, const Player& q, bool tint, bool queue = true) {
-    for (int c = 0; c < NCOL; c++) stw(s, o, (size_t)(W_COL0 + c) * ws, q.col[c]);
+TE_HD void store_player(uint32_t* s, uint32_t o, size_t ws, const Player& q, bool tint, bool queue = true, int mem = MEM_STREAM) {
+    for (int c = 0; c < NCOL; c++) stw(s, o, (size_t)(W_COL0 + c) * ws, q.col[c], mem);
     if (tint)
         for (int k = 0; k < 3; k++)
-            for (int c = 0; c < NCOL; c++) stw(s, o, (size_t)(W_TINT0 + 10 * k + c) * ws, q.tint[k][c]);
+            for (int c = 0; c < NCOL; c++) stw(s, o, (size_t)(W_TINT0 + 10 * k + c) * ws, q.tint[k][c], mem);
     stw(s, o, (size_t)W_PIECE * ws, (uint32_t)q.kind | ((uint32_t)q.rot << 3) | ((uint32_t)(q.x + 4) << 5) | ((uint32_t)q.y << 9) |
                               ((uint32_t)q.next << 14) | ((uint32_t)q.dead << 17) | ((uint32_t)q.lock_armed << 18) |
-                              ((uint32_t)(q.reward & 255) << 19));
+                              ((uint32_t)(q.reward & 255) << 19), mem);
     stw(s, o, (size_t)W_MISC * ws, (uint32_t)(q.inc_count & 255) | ((uint32_t)(q.combo_count & 255) << 8) |
-                             ((uint32_t)(q.line_count & 255) << 16) | ((uint32_t)q.qlen << 24) | ((uint32_t)q.q_overflow << 28));
-    stw(s, o, (size_t)W_TIME * ws, (uint32_t)q.time_ms);
-    stw(s, o, (size_t)W_DROPCOMBO * ws, ((uint32_t)q.drop_delay & 0xFFFF) | (q.combo_remaining << 16));
-    stw(s, o, (size_t)W_DROP_TIME * ws, (uint32_t)q.drop_time);
-    stw(s, o, (size_t)W_SPEEDUP_TIME * ws, (uint32_t)q.speedup_time);
-    stw(s, o, (size_t)W_LOCK_TIME * ws, (uint32_t)q.lock_time);
-    stw(s, o, (size_t)W_COMBO_START * ws, (uint32_t)q.combo_start);
-    stw(s, o, (size_t)W_COMBO_TIME * ws, (uint32_t)q.combo_time);
-    if (queue) stw(s, o, (size_t)W_INCOMING * ws, f2u(q.incoming));
-    stw(s, o, (size_t)W_MIN_REMAINING * ws, (uint32_t)q.min_remaining);
-    stw(s, o, (size_t)W_PIECE_DRAWS * ws, q.piece_draws);
-    if (queue) stw(s, o, (size_t)W_HOLE_DRAWS * ws, q.hole_draws);
-    stw(s, o, (size_t)W_PIECE_GROUP * ws, q.pgroup);
-    stw(s, o, (size_t)W_STATS0 * ws, (q.lines_sent & 0xFFFF) | (q.lines_cleared << 16));
-    stw(s, o, (size_t)W_STATS1 * ws, (q.lines_blocked & 0xFFFF) | (q.max_combo << 16));
-    stw(s, o, (size_t)W_STATS2 * ws, (q.lines_seen & 0xFFFF) | (q.garbage_cleared << 16));
+                             ((uint32_t)(q.line_count & 255) << 16) | ((uint32_t)q.qlen << 24) | ((uint32_t)q.q_overflow << 28), mem);
+    stw(s, o, (size_t)W_TIME * ws, (uint32_t)q.time_ms, mem);
+    stw(s, o, (size_t)W_DROPCOMBO * ws, ((uint32_t)q.drop_delay & 0xFFFF) | (q.combo_remaining << 16), mem);
+    stw(s, o, (size_t)W_DROP_TIME * ws, (uint32_t)q.drop_time, mem);
+    stw(s, o, (size_t)W_SPEEDUP_TIME * ws, (uint32_t)q.speedup_time, mem);
+    stw(s, o, (size_t)W_LOCK_TIME * ws, (uint32_t)q.lock_time, mem);
+    stw(s, o, (size_t)W_COMBO_START * ws, (uint32_t)q.combo_start, mem);
+    stw(s, o, (size_t)W_COMBO_TIME * ws, (uint32_t)q.combo_time, mem);
+    if (queue) stw(s, o, (size_t)W_INCOMING * ws, f2u(q.incoming), mem);
+    stw(s, o, (size_t)W_MIN_REMAINING * ws, (uint32_t)q.min_remaining, mem);
+    stw(s, o, (size_t)W_PIECE_DRAWS * ws, q.piece_draws, mem);
+    if (queue) stw(s, o, (size_t)W_HOLE_DRAWS * ws, q.hole_draws, mem);
+    stw(s, o, (size_t)W_PIECE_GROUP * ws, q.pgroup, mem);
+    stw(s, o, (size_t)W_STATS0 * ws, (q.lines_sent & 0xFFFF) | (q.lines_cleared << 16), mem);
+    stw(s, o, (size_t)W_STATS1 * ws, (q.lines_blocked & 0xFFFF) | (q.max_combo << 16), mem);
+    stw(s, o, (size_t)W_STATS2 * ws, (q.lines_seen & 0xFFFF) | (q.garbage_cleared << 16), mem);
     if (queue && (q.q_loaded || q.qlen > 0)) {
         for (int i = 0; i < FIFO_CAP / 2; i++)
-            stw(s, o, (size_t)(W_FIFO_COUNT0 + i) * ws, ((uint32_t)q.qcount[2 * i] & 0xFFFF) | ((uint32_t)q.qcount[2 * i + 1] << 16));
-        for (int i = 0; i < FIFO_CAP; i++) stw(s, o, (size_t)(W_FIFO_DELAY0 + i) * ws, (uint32_t)q.qdelay[i]);
+            stw(s, o, (size_t)(W_FIFO_COUNT0 + i) * ws, ((uint32_t)q.qcount[2 * i] & 0xFFFF) | ((uint32_t)q.qcount[2 * i + 1] << 16), mem);
+        for (int i = 0; i < FIFO_CAP; i++) stw(s, o, (size_t)(W_FIFO_DELAY0 + i) * ws, (uint32_t)q.qdelay[i], mem);
     }
 }
 
 template <int P>
-TE_HD void store_game_words(const Ref& gr, const Game<P>& g, bool counters = false) {
-    stw(gr.s, gr.o, (size_t)G_META * gr.ws, g.seed16 | ((uint32_t)g.round_over << 16) | ((uint32_t)(g.last_winner + 1) << 17) | (g.flags << 21));
-    stw(gr.s, gr.o, (size_t)G_EPISODE * gr.ws, g.episode);
-    if (counters) stw(gr.s, gr.o, (size_t)G_STEPS * gr.ws, g.steps);
+TE_HD void store_game_words(const Ref& gr, const Game<P>& g, bool counters = false, int mem = MEM_STREAM) {
+    stw(gr.s, gr.o, (size_t)G_META * gr.ws, g.seed16 | ((uint32_t)g.round_over << 16) | ((uint32_t)(g.last_winner + 1) << 17) | (g.flags << 21), mem);
+    stw(gr.s, gr.o, (size_t)G_EPISODE * gr.ws, g.episode, mem);
+    if (counters) stw(gr.s, gr.o, (size_t)G_STEPS * gr.ws, g.steps, mem);
     // lines are cleared / sent in a few steps per thousand under a random policy: these two words are updated only then, by
     // a fire-and-forget atomic add (no return value: the wave does not wait for the memory round trip at the end of its
     // step — a dependent load + store there made the slowest wave, and with it every launch, ~0.8 us longer)
@@ -327,14 +348,14 @@ TE_HD void store_game_words(const Ref& gr, const Game<P>& g, bool counters = fal
 }
 
 template <int P>
-TE_HD void store_game(const Geo& geo_in, size_t slot, const Game<P>& g, bool tint = false, bool queue = true, bool counters = false) {
+TE_HD void store_game(const Geo& geo_in, size_t slot, const Game<P>& g, bool tint = false, bool queue = true, bool counters = false, int mem = MEM_STREAM) {
     Geo geo = geo_in;
     geo.P = P;
-    store_game_words<P>(game_ref(geo, slot), g, counters);
+    store_game_words<P>(game_ref(geo, slot), g, counters, mem);
     TE_UNROLL
     for (int p = 0; p < P; p++) {
         const Ref r = board_ref(geo, p, slot);
-        store_player(r.s, r.o, r.ws, g.pl[p], tint, queue);
+        store_player(r.s, r.o, r.ws, g.pl[p], tint, queue, mem);
     }
 }
 
@@ -518,7 +539,7 @@ TE_HD void q_pop_front(Player& q) {
 
 // Garbage.cpp:22-24 add (initialDelay 1000)
 TE_HD void q_add(Player& q, int amount, int32_t t, uint32_t& status) {
-    if (q.qlen >= FIFO_CAP) { q.q_overflow = 1; status |= ST_FIFO_OVERFLOW; return; }
+    if (q.qlen >= FIFO_CAP) { q.q_overflow |= ERR_FIFO; status |= ST_FIFO_OVERFLOW; return; }
     for (int i = 0; i < FIFO_CAP; i++)
         if (i == q.qlen) { q.qcount[i] = (int16_t)amount; q.qdelay[i] = t + 1000; }
     q.qlen++;
@@ -1252,6 +1273,18 @@ TE_HD void share_lines(Game<P>& g, int sender, int amount) {
         if (p != sender) g.pl[p].incoming = g.pl[p].incoming + each;
 }
 
+// a capacity error of this step (status bits) or of an earlier one (board bits) ends the game's round: see ERR_*
+template <int P>
+TE_HD bool confine_errors(Game<P>& g) {
+    int err = 0;
+    TE_UNROLL
+    for (int p = 0; p < P; p++) {
+        if (g.status & ST_STREAM_EXHAUSTED) g.pl[p].q_overflow |= ERR_STREAM;      // the seed, and with it the tables, is the game's
+        err |= g.pl[p].q_overflow;
+    }
+    return err != 0;
+}
+
 // PythonHandle.cpp:149-188 finish_actions (+ action_finish :114-122); returns round_over
 template <int P>
 TE_HD int finish_game(const Ctx& cx, Game<P>& g, int ms) {
@@ -1279,6 +1312,7 @@ TE_HD int finish_game(const Ctx& cx, Game<P>& g, int ms) {
         q.lines_seen = q.lines_cleared;
         q.inc_count = cx.queue ? (q_total(q) & 255) : 0;
     }
+    if (confine_errors<P>(g)) { g.round_over = 1; return 1; }
     if ((P > 1 && alive < 2) || !alive) { g.round_over = 1; return 1; }
     return 0;
 }
@@ -1295,7 +1329,7 @@ TE_HD int finish_game(const Ctx& cx, Game<P>& g, int ms) {
 //      player 1's garbage queue in the same step (PythonHandle.cpp:160-180).
 //   C  after the third exchange: player 1's tick lines reach player 0, winner / round_over (:182-187).
 // Exchange word: sent[0:16) | DIED[16] | DEAD_NOW[17] | RAN[18].
-constexpr uint32_t XW_DIED = 1u << 16, XW_DEAD_NOW = 1u << 17, XW_RAN = 1u << 18;
+constexpr uint32_t XW_DIED = 1u << 16, XW_DEAD_NOW = 1u << 17, XW_RAN = 1u << 18, XW_ERR = 1u << 19;
 constexpr uint32_t SPLIT_SIDE = 1u, SPLIT_OPP_DEAD = 2u, SPLIT_ON = 4u;
 TE_HD int xw_sent(uint32_t w) { return (int)(w & 0xFFFFu); }
 
@@ -1311,7 +1345,7 @@ TE_HD uint32_t split_settle(const Ctx& cx, Game<1>& g) {
 // stage B: my player's delayCheck.  `first_in` = lines that reach me before my tick.  Returns my word.
 TE_HD uint32_t split_tick(const Ctx& cx, Game<1>& g, int ms, int lines_in) {
     Player& q = g.pl[0];
-    if (g.round_over) return q.dead ? XW_DEAD_NOW : 0u;
+    if (g.round_over) return (q.dead ? XW_DEAD_NOW : 0u) | (q.q_overflow ? XW_ERR : 0u);
     if (lines_in > 0) q.incoming = q.incoming + (float)lines_in / 1.0f;       // amount / (P - 1), P = 2
     uint32_t w = 0;
     if (!q.dead) {
@@ -1324,17 +1358,18 @@ TE_HD uint32_t split_tick(const Ctx& cx, Game<1>& g, int ms, int lines_in) {
             q.inc_count = q_total(q) & 255;
         }
     }
-    return w | (q.dead ? XW_DEAD_NOW : 0u);
+    if (g.status & ST_STREAM_EXHAUSTED) q.q_overflow |= ERR_STREAM;
+    return w | (q.dead ? XW_DEAD_NOW : 0u) | (q.q_overflow ? XW_ERR : 0u);
 }
 
 // stage C: lines that arrive after my tick, then PythonHandle.cpp:182-187 with the opponent's final dead flag
-TE_HD int split_finish(Game<1>& g, int lines_in, bool opp_dead) {
+TE_HD int split_finish(Game<1>& g, int lines_in, bool opp_dead, bool opp_err = false) {
     Player& q = g.pl[0];
     if (g.round_over) return 1;
     if (lines_in > 0) q.incoming = q.incoming + (float)lines_in / 1.0f;
     g.flags = (g.flags & ~SPLIT_OPP_DEAD) | (opp_dead ? SPLIT_OPP_DEAD : 0u);
     int alive = (q.dead ? 0 : 1) + (opp_dead ? 0 : 1);
-    if (alive < 2) { g.round_over = 1; return 1; }
+    if (alive < 2 || q.q_overflow || opp_err) { g.round_over = 1; return 1; }      // a capacity error on either side ends the round (ERR_*)
     return 0;
 }
 

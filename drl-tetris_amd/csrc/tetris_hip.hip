@@ -53,6 +53,38 @@ __global__ __launch_bounds__(256) void k_game(KArgs a) {
     TE_STAMP(14); TE_STAMP_RT(15);
 }
 
+// Chained launches of the built-in rollout (one env-step per launch).  A game's step E depends on nothing but the same game's
+// step E - 1, yet launches on one stream are separated by a full barrier: launch E waits for the SLOWEST wave of launch E - 1
+// plus the kernel boundary (~1.4 us of a ~5.7 us launch period, profiles/).  Here consecutive launches go to two streams
+// alternately, so launch E is dispatched while E - 1 still runs, and the dependence is enforced per WAVE (one workgroup = one
+// wave = 64 games): wave w of launch E polls an epoch word until wave w of launch E - 1 has published E - 1.  Every state
+// load / store is agent-scope (`sc1`: written through, read past the per-XCD L2), the storing wave drains its stores
+// (`s_waitcnt vmcnt(0)`) before it publishes — the measured-valid hand-off of MI355X_MICROARCH.md.  Spins are bounded: a wave
+// that gives up poisons its epoch word, raises F_CHAIN and leaves its games untouched, and the host reports an error.
+template <int P>
+__global__ __launch_bounds__(64) void k_chain(KArgs a) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_shapes[SHAPE_WORDS];
+    const int lane = threadIdx.x, wave = blockIdx.x;
+    const int i = wave * 64 + lane;
+    const bool active = i < a.n;
+    LaneCounters cnt = {0, 0, 0, 0};
+    const uint32_t shape_word = d_shape_table.s[lane];
+    Game<P> g;
+    // the policy draw of this step depends on kernel arguments only: its 40 dependent multiplies run while the wave waits
+    if (active) policy_draw(a, (uint32_t)i, a.first_step, g.draw0, g.draw1);
+    const uint32_t d0 = g.draw0, d1 = g.draw1;
+    if (!chain_wait(a, (uint32_t)wave)) {
+        if (lane == 0) { ((volatile uint32_t*)a.status)[F_CHAIN] = 1u; st_agent(a.chain + wave, CHAIN_POISON); }
+        return;
+    }
+    if (active) { load_game<P>(geo_of(a), (size_t)i, g, false, P > 1, true, MEM_AGENT); g.draw0 = d0; g.draw1 = d1; }
+    s_shapes[lane] = shape_word;
+    __builtin_amdgcn_wave_barrier();
+    if (active) game_run<P, M_ROLLOUT, false, MEM_AGENT>(a, i, s_shapes, g, cnt);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every store (and counter atomic) of this wave has been acknowledged
+    if (lane == 0) st_agent(a.chain + wave, a.epoch);
+}
+
 // Sums the per-game cumulative rollout counters (G_STEPS, G_EPISODE, G_LINES, G_SENT): run once before and once
 // after a rollout, outside its timed region, instead of any cross-lane reduction inside the step
 // kernel (4096 same-address atomics per launch cost ~28 us; a shuffle + LDS + read-modify-write tail
@@ -144,7 +176,7 @@ __global__ __launch_bounds__(256) void k_duo(KArgs a) {
             const uint32_t opp_b = side == 0 ? x1 : x0;
             const int in = (side == 0 && !(opp_b & XW_DIED)) ? xw_sent(opp_b) : 0;
             g.flags = (uint32_t)side;
-            done = split_finish(g, in, (opp_b & XW_DEAD_NOW) != 0);
+            done = split_finish(g, in, (opp_b & XW_DEAD_NOW) != 0, (opp_b & XW_ERR) != 0);
             out_reward = q.reward; out_dead = q.dead;                  // what the step reports: the state BEFORE an auto-reset
             if (ROLL) {
                 g.steps++;
@@ -304,55 +336,67 @@ __global__ __launch_bounds__(BLOCK) void k_observe_packed(Geo geo, int n, const 
     }
 }
 
-// BASELINE config 4.  One workgroup = ENUM_BOARDS boards x 40 placement lanes.  Phase A: lanes 0..10 of a board fetch its ten
-// columns and piece word (ONE global load per word and board instead of one per placement).  Phase B: the board's lanes fill
-// its BoardPre in LDS (tetris_kernels.h) — band window and depth strip by the column lanes (LDS atomics / byte writes),
-// prefix / suffix ANDs by lanes 10..31.  Phase C: every lane places its (rotation, column) from ~10 LDS reads.
-// PLANAR: after[c][lanes] — store c of a wave is 256 contiguous bytes; else after[lane][10] as tetris_enumerate_drops documents.
+// BASELINE config 4.  One workgroup = ENUM_BOARDS boards x 10 lanes; lane (board, xi) places the piece in column xi for the four
+// rotations in turn.  Phase A: a board's ten lanes fetch its ten columns (ONE global load per word and board) and its piece
+// word.  Phase B: they fill its BoardPre in LDS (tetris_kernels.h): band window (LDS atomics), depth strip (byte writes), prefix /
+// suffix ANDs.  Phase C: four placements per lane from ~10 LDS reads each.  16 384 boards = 2 560 waves, all resident at once.
+// PLANAR: every output is rotation-major — valid / land_y / cleared [4][n][10], after [10][4][n][10] — so that each store of a
+// wave is 64 consecutive elements; else the layouts tetris_enumerate_drops documents ([n][4][10] and [n][4][10][10]).
 template <int P, bool PLANAR>
 __global__ __launch_bounds__(ENUM_BLOCK) void k_enumerate(Geo geo, int n, const int32_t* idx, const uint8_t* player, int H,
                                                           uint8_t* valid, int8_t* land_y, uint8_t* cleared, uint32_t* after) {
     __shared__ __attribute__((aligned(16))) uint32_t s_pre[ENUM_BOARDS][PRE_WORDS];
     __shared__ __attribute__((aligned(16))) uint32_t s_shapes[SHAPE_WORDS];
-    const int tid = threadIdx.x, b = tid / 40, j = tid - b * 40;
+    const int tid = threadIdx.x, b = tid / 10, j = tid - b * 10;
     const int i = blockIdx.x * ENUM_BOARDS + b;                  // board of this lane
     const bool live = i < n;
     uint32_t* pre = s_pre[b];
     const uint32_t floor_bits = ~0u << H;
     if (tid < SHAPE_WORDS) s_shapes[tid] = d_shape_table.s[tid];
     uint32_t mine = 0;
-    if (live && j <= NCOL) {
+    if (live) {
         const Ref br = board_ref(geo, safe_player(player, i, P), safe_slot(idx, i, (int)geo.n_games));
-        mine = word_at(br, j < NCOL ? W_COL0 + j : W_PIECE);
-        pre[j < NCOL ? PRE_COL + j : PRE_PIECE] = mine;
+        mine = word_at(br, W_COL0 + j);
+        pre[PRE_COL + j] = mine;
+        if (j == 0) {
+            pre[PRE_PIECE] = word_at(br, W_PIECE);
+            pre[PRE_BAND] = 0xFFu; pre[PRE_BAND + 1] = 0xFFFF0000u;
+        }
+        if (j >= 1 && j < 5) pre[PRE_STRIP + (j - 1)] = 0u;
     }
-    if (j == 11) { pre[PRE_BAND] = 0xFFu; pre[PRE_BAND + 1] = 0xFFFF0000u; }
-    if (j >= 12 && j < 16) pre[PRE_STRIP + (j - 12)] = 0u;
     __syncthreads();
     if (live) {
-        if (j < NCOL) {
-            int word;
-            const uint32_t bits = pre_band_bits(mine, floor_bits, j, word);
-            atomicOr(&pre[PRE_BAND + word], bits);
-            ((uint8_t*)(pre + PRE_STRIP))[j + 2] = (uint8_t)pre_depth(mine, floor_bits);
-        } else if (j < 21)
-            pre[PRE_PRE + (j - 10)] = pre_and_below(pre + PRE_COL, j - 10);
-        else if (j < 32)
-            pre[PRE_SUF + (j - 21)] = pre_and_from(pre + PRE_COL, j - 21);
+        int word;
+        const uint32_t bits = pre_band_bits(mine, floor_bits, j, word);
+        atomicOr(&pre[PRE_BAND + word], bits);
+        ((uint8_t*)(pre + PRE_STRIP))[j + 2] = (uint8_t)pre_depth(mine, floor_bits);
+        pre[PRE_PRE + j] = pre_and_below(pre + PRE_COL, j);
+        pre[PRE_SUF + j] = pre_and_from(pre + PRE_COL, j);
+        if (j == 0) { pre[PRE_PRE + NCOL] = pre_and_below(pre + PRE_COL, NCOL); pre[PRE_SUF + NCOL] = ~0u; }
     }
     __syncthreads();
     if (!live) return;
-    const size_t t = (size_t)i * 40 + j;
-    const Placement pl = enum_place(pre, s_shapes, H, j / 10, j % 10);
-    valid[t] = (uint8_t)pl.ok;
-    land_y[t] = (int8_t)pl.y;
-    cleared[t] = (uint8_t)pl.cleared;
-    if (after) {
-        const size_t lanes = (size_t)n * 40;
-        for (int c = 0; c < NCOL; c++) {
-            const uint32_t v = enum_after_col(pre, pl, c);
-            if (PLANAR) __builtin_nontemporal_store(v, &after[(size_t)c * lanes + t]);
-            else __builtin_nontemporal_store(v, &after[t * NCOL + c]);
+#if defined(TE_ENUM_EXP) && TE_ENUM_EXP == 1
+    if (pre[PRE_BAND] == 12345u) valid[0] = 1;      // experiment: precompute only
+    return;
+#endif
+    const size_t boards = (size_t)n;
+    for (int r = 0; r < 4; r++) {
+        const Placement pl = enum_place(pre, s_shapes, H, r, j);
+        const size_t t = PLANAR ? ((size_t)r * boards + i) * 10 + j : ((size_t)i * 4 + r) * 10 + j;
+#if defined(TE_ENUM_EXP) && TE_ENUM_EXP == 3
+        if (pl.ok + pl.y + pl.cleared == 12345) valid[t] = 1;      // experiment: no byte stores
+#else
+        valid[t] = (uint8_t)pl.ok;
+        land_y[t] = (int8_t)pl.y;
+        cleared[t] = (uint8_t)pl.cleared;
+#endif
+        if (after) {
+            for (int c = 0; c < NCOL; c++) {
+                const uint32_t v = enum_after_col(pre, pl, c);
+                if (PLANAR) __builtin_nontemporal_store(v, &after[((size_t)c * 4 + r) * boards * 10 + (size_t)i * 10 + j]);
+                else after[t * NCOL + c] = v;             // 40 contiguous bytes per lane: left to the L2 to merge
+            }
         }
     }
 }
@@ -523,6 +567,12 @@ struct tetris_batch {
     int use_duo = 1;                     // two-player rollout / step_rt through k_duo (TETRIS_NO_DUO=1 in the environment: k_game<2>)
     uint32_t* d_shadow = nullptr;        // split mode, side 1
     hipStream_t own_stream = nullptr;
+    // chained launches (k_chain): two extra streams, one epoch word per wave, the number of the last chained launch
+    hipStream_t chain_stream[2] = {nullptr, nullptr};
+    hipEvent_t chain_ev[3] = {nullptr, nullptr, nullptr};
+    uint32_t* d_chain = nullptr;
+    uint32_t chain_epoch = 0;
+    int use_chain = 1;                   // TETRIS_NO_CHAIN=1 in the environment: every rollout launch on the batch's one stream
     // Run-ahead gate of the asynchronous entry points: every GATE_GROUP launches an event is recorded; before a new group is
     // enqueued the host waits for the event of the group before the previous one.  At most 2 * GATE_GROUP + 1 launches are
     // therefore in flight whose flag words the host has not seen; `margin` is sized for that many steps.
@@ -581,7 +631,9 @@ static int service_flags(tetris_batch* b) {
     const uint32_t want = f[F_EXTEND];
     if (want) {
         std::lock_guard<std::mutex> lock(g_tab_mutex);
-        if (want >= (uint32_t)b->tab->n_chunks * CHUNK) {        // not yet answered (requests carry the size their kernel saw)
+        // not yet answered (requests carry the size their kernel saw); at MAX_CHUNKS the tables stay as they are and a game
+        // that outruns them is ended with ERR_STREAM
+        if (want >= (uint32_t)b->tab->n_chunks * CHUNK && b->tab->n_chunks < MAX_CHUNKS) {
             int rc = tables_extend(b->tab, b->stream);
             if (rc) return rc;
         }
@@ -612,8 +664,8 @@ static int finish_call(tetris_batch* b) {
     HIP_TRY(hipStreamSynchronize(b->stream));
     b->gate_count = 0; b->gate_pending[0] = b->gate_pending[1] = 0;
     volatile uint32_t* f = b->flags;
-    if (f[F_EXHAUSTED]) return fail(TETRIS_E_STREAM, "an episode ran past the RNG tables; state is invalid");
-    if (f[F_FIFO]) return fail(TETRIS_E_FIFO, "garbage FIFO overflow (> 8 pending packets); state is invalid");
+    // (F_EXHAUSTED / F_FIFO: capacity errors are confined to the games they happened in — tetris_take_errors)
+    if (f[F_CHAIN]) return fail(TETRIS_E_HIP, "a wave of a chained launch gave up waiting for its predecessor; state is invalid");
     int rc = service_flags(b);                                  // before the argument error below: an extend request is never dropped
     if (rc) return rc;
     if (f[F_BADARG]) {
@@ -696,6 +748,9 @@ int tetris_destroy(tetris_batch* b) {
     if (b->flags) (void)hipHostFree(b->flags);
     if (b->h_counters) (void)hipHostFree(b->h_counters);
     for (hipEvent_t e : b->gate_ev) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : b->chain_ev) if (e) (void)hipEventDestroy(e);
+    for (hipStream_t st : b->chain_stream) if (st) (void)hipStreamDestroy(st);
+    (void)hipFree(b->d_chain);
     Stage* all[] = {&b->s_idx, &b->s_in0, &b->s_in1, &b->s_in2, &b->s_out0, &b->s_out1, &b->s_out2, &b->s_big, &b->s_act0, &b->s_act1, &b->s_act2};
     for (Stage* s : all) s->release();
     if (b->ev0) (void)hipEventDestroy(b->ev0);
@@ -730,6 +785,7 @@ static int create_impl(tetris_batch** out, int n_games, int n_players, int heigh
     b->device = device; b->N = n_games; b->P = n_players; b->H = height;
     b->tint = (flags & TETRIS_FLAG_COLOURS) ? 1 : 0;
     { const char* e = getenv("TETRIS_NO_DUO"); b->use_duo = !(e && e[0] == '1'); }
+    { const char* e = getenv("TETRIS_NO_CHAIN"); b->use_chain = !(e && e[0] == '1'); }
     b->nw = b->tint ? NWORDS_TINT : NWORDS;
 #define CREATE_TRY(expr)                                                                    \
     do {                                                                                    \
@@ -743,6 +799,13 @@ static int create_impl(tetris_batch** out, int n_games, int n_players, int heigh
     b->own_stream = b->stream;
     CREATE_TRY(hipEventCreate(&b->ev0));
     CREATE_TRY(hipEventCreate(&b->ev1));
+    for (int k = 0; k < 2; k++) CREATE_TRY(hipStreamCreateWithFlags(&b->chain_stream[k], hipStreamNonBlocking));
+    for (int k = 0; k < 3; k++) CREATE_TRY(hipEventCreateWithFlags(&b->chain_ev[k], hipEventDisableTiming));
+    {
+        const size_t chain_bytes = (((size_t)n_games + 63) / 64) * sizeof(uint32_t);
+        CREATE_TRY(hipMalloc((void**)&b->d_chain, chain_bytes));
+        CREATE_TRY(hipMemsetAsync(b->d_chain, 0, chain_bytes, b->stream));
+    }
     CREATE_TRY(hipEventCreateWithFlags(&b->gate_ev[0], hipEventDisableTiming));
     CREATE_TRY(hipEventCreateWithFlags(&b->gate_ev[1], hipEventDisableTiming));
     const size_t state_bytes = state_words((size_t)n_games, n_players, b->nw) * 4, gstate_bytes = gstate_words((size_t)n_games) * 4;
@@ -856,6 +919,17 @@ int tetris_rollout_totals(tetris_batch* b, uint64_t totals[4]) {
     HIP_TRY(hipMemcpyAsync(b->h_counters, b->d_counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, b->stream));
     if ((rc = finish_call(b))) return rc;
     for (int k = 0; k < 4; k++) totals[k] = b->h_counters[k];
+    return TETRIS_OK;
+}
+
+int tetris_take_errors(tetris_batch* b, uint32_t* bits) {
+    int rc = check_batch(b);
+    if (rc) return rc;
+    if (!bits) return fail(TETRIS_E_ARG, "bits is NULL");
+    if ((rc = finish_call(b))) return rc;
+    volatile uint32_t* f = b->flags;
+    *bits = (f[F_FIFO] ? TETRIS_ERR_FIFO : 0u) | (f[F_EXHAUSTED] ? TETRIS_ERR_STREAM : 0u);
+    f[F_FIFO] = 0; f[F_EXHAUSTED] = 0;
     return TETRIS_OK;
 }
 
@@ -1216,11 +1290,11 @@ int tetris_enumerate_drops_dev_ex(tetris_batch* b, const int32_t* d_idx, int n, 
     if (rc) return rc;
     if (!d_valid || !d_land_y || !d_cleared) return fail(TETRIS_E_ARG, "valid/land_y/cleared are NULL");
     if (n < 0 || (!d_idx && n > b->N)) return fail(TETRIS_E_ARG, "n out of range");
-    if (flags & ~TETRIS_ENUM_AFTER_PLANAR) return fail(TETRIS_E_ARG, "unknown flag");
+    if (flags & ~TETRIS_ENUM_PLANAR) return fail(TETRIS_E_ARG, "unknown flag");
     if (n == 0) return TETRIS_OK;
     dim3 grid((unsigned)((n + ENUM_BOARDS - 1) / ENUM_BOARDS)), block(ENUM_BLOCK);
     const Geo geo = geo_of_batch(b);
-    const bool planar = (flags & TETRIS_ENUM_AFTER_PLANAR) != 0;
+    const bool planar = (flags & TETRIS_ENUM_PLANAR) != 0;
 #define LAUNCH_ENUM(PP, PL) hipLaunchKernelGGL((k_enumerate<PP, PL>), grid, block, 0, b->stream, geo, n, d_idx, d_player, b->H, d_valid, \
                                                d_land_y, d_cleared, d_after)
     if (b->P == 1) { if (planar) LAUNCH_ENUM(1, true); else LAUNCH_ENUM(1, false); }
@@ -1332,13 +1406,39 @@ int tetris_rollout_launch(tetris_batch* b, int launches, int steps_per_launch, u
     group = group < 1 ? 1 : (group > GATE_GROUP ? GATE_GROUP : group);
     const uint32_t need = (uint32_t)(2 * steps_per_launch * (2 * group + 2) + 16);
     if (b->margin < need) b->margin = need;
+    // single-player batches on their own stream: chained launches (k_chain) — consecutive launches alternate between two
+    // streams and each wave waits for its own predecessor only, not for the slowest wave of the whole previous launch
+    const bool chained = b->use_chain && b->P == 1 && !b->tint && !b->split && b->stream == b->own_stream && steps_per_launch >= 1;
     HIP_TRY(hipEventRecord(b->ev0, b->stream));
+    if (chained) {
+        // both chain streams start behind everything the batch's stream has been given so far
+        HIP_TRY(hipEventRecord(b->chain_ev[2], b->stream));
+        for (int k = 0; k < 2; k++) HIP_TRY(hipStreamWaitEvent(b->chain_stream[k], b->chain_ev[2], 0));
+    }
+    hipStream_t const home = b->stream;
+    struct StreamGuard {                          // base_args / launch_game / gate_launch work on b->stream
+        tetris_batch* b; hipStream_t home;
+        ~StreamGuard() { b->stream = home; }
+    } stream_guard{b, home};
     for (int l = 0; l < launches; l++) {
+        if (chained) b->stream = b->chain_stream[l & 1];
         if ((rc = gate_launch(b, group))) return rc;
         KArgs a = base_args(b, b->N, nullptr);
         a.ms = ms; a.steps = steps_per_launch; a.policy_seed = policy_seed;
         a.first_step = first_step + (uint64_t)l * (uint64_t)steps_per_launch;
-        if ((rc = launch_game<M_ROLLOUT>(b, a))) return rc;
+        if (chained) {
+            a.chain = b->d_chain; a.epoch = ++b->chain_epoch;
+            hipLaunchKernelGGL((k_chain<1>), dim3((unsigned)((b->N + 63) / 64)), dim3(64), 0, b->stream, a);
+            HIP_TRY(hipGetLastError());
+        } else if ((rc = launch_game<M_ROLLOUT>(b, a)))
+            return rc;
+    }
+    b->stream = home;
+    if (chained) {                                // the batch's stream continues behind both chain streams
+        for (int k = 0; k < 2; k++) {
+            HIP_TRY(hipEventRecord(b->chain_ev[k], b->chain_stream[k]));
+            HIP_TRY(hipStreamWaitEvent(home, b->chain_ev[k], 0));
+        }
     }
     HIP_TRY(hipEventRecord(b->ev1, b->stream));
     if ((rc = finish_call(b))) return rc;

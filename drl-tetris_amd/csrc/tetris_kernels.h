@@ -41,6 +41,8 @@ struct KArgs {
     unsigned long long first_step;
     unsigned long long* counters;
     uint32_t game_offset;     // global id of slot 0 (rollout policy / seed schedule)
+    uint32_t* chain;          // chained launches: one epoch word per wave (NULL = launches are ordered by the stream)
+    uint32_t epoch;           // chained launches: this launch's number; its waves wait for epoch - 1 and publish epoch
     uint32_t* shadow;         // split mode, side 1: post-settle state of the speculative loop-1 pass
     const uint32_t* xw;       // split mode: exchange words [4][n]: my A, opponent's A, player 0's B, player 1's B
     uint32_t* xout;           // split mode: this stage's word per board [n]
@@ -79,6 +81,25 @@ TE_HD void report_status(const KArgs& a, uint32_t st) {
     if (st & ST_STREAM_EXHAUSTED) f[F_EXHAUSTED] = 1u;
     if (st & ST_FIFO_OVERFLOW) f[F_FIFO] = 1u;
     if (st & ST_BAD_ARGUMENT) f[F_BADARG] = 1u;
+}
+
+// ---- chained launches (tetris_hip.hip: k_chain): the hand-over of a wave's 64 games from launch E - 1 to launch E
+constexpr uint32_t CHAIN_POISON = 0xFFFFFFFFu;      // a wave gave up waiting: every later launch's wave passes the poison on
+constexpr int CHAIN_SPIN_LIMIT = 1 << 18;           // polls before a wave gives up (each followed by a short sleep): ~50 ms
+
+// true when the state of this wave's games as launch E - 1 left it is visible (their stores were `sc1` and drained before the
+// epoch word was written, and the word is polled with an `sc1` load: MI355X_MICROARCH.md, valid forms of an inter-workgroup hand-off)
+TE_HD bool chain_wait(const KArgs& a, uint32_t wave) {
+    const uint32_t want = a.epoch - 1u;
+    for (int spin = 0; spin < CHAIN_SPIN_LIMIT; spin++) {
+        const uint32_t v = ld_agent(a.chain + wave);
+        if (v == want) return true;
+        if (v == CHAIN_POISON) break;
+#if defined(__HIP_DEVICE_COMPILE__)
+        __builtin_amdgcn_s_sleep(2);
+#endif
+    }
+    return false;
 }
 
 TE_HD Ctx make_ctx(const KArgs& a, const uint32_t* shapes, bool tint = false, bool queue = true) {
@@ -141,11 +162,11 @@ TE_HD void policy_draw(const KArgs& a, uint32_t slot, unsigned long long step, u
 #endif
 }
 
-template <int P, int MODE, bool TINT = false>
+template <int P, int MODE, bool TINT = false, int MEM = MEM_STREAM>
 TE_HD void game_load(const KArgs& a, int i, Game<P>& g) {
     const size_t slot = a.idx ? (size_t)a.idx[i] : (size_t)i;
     if (MODE != M_INIT && MODE != M_SPLIT_INIT)
-        load_game<P>(geo_of(a), slot, g, TINT, P > 1 || MODE == M_SPLIT_RESET, MODE == M_ROLLOUT);   // split batches: 1-player layout WITH a queue
+        load_game<P>(geo_of(a), slot, g, TINT, P > 1 || MODE == M_SPLIT_RESET, MODE == M_ROLLOUT, MEM);   // split batches: 1-player layout WITH a queue
     // the first step's draw depends on kernel arguments only: its 40 dependent multiplies run while the state loads are in flight
     if (MODE == M_ROLLOUT) policy_draw(a, (uint32_t)slot, a.first_step, g.draw0, g.draw1);
     // (r, t) actions: the three action bytes are requested together with the state, not after it has arrived
@@ -153,7 +174,7 @@ TE_HD void game_load(const KArgs& a, int i, Game<P>& g) {
 }
 
 // Phase 2: step and store.
-template <int P, int MODE, bool TINT = false>
+template <int P, int MODE, bool TINT = false, int MEM = MEM_STREAM>
 TE_HD void game_run(const KArgs& a, int i, const uint32_t* shapes, Game<P>& g, LaneCounters& cnt) {
     const size_t slot = a.idx ? (size_t)a.idx[i] : (size_t)i;
     Ctx cx = make_ctx(a, shapes, TINT, P > 1 || MODE == M_SPLIT_INIT || MODE == M_SPLIT_RESET);
@@ -235,7 +256,7 @@ TE_HD void game_run(const KArgs& a, int i, const uint32_t* shapes, Game<P>& g, L
         }
     }
     store_game<P>(geo_of(a), slot, g, TINT, P > 1 || MODE == M_SPLIT_INIT || MODE == M_SPLIT_RESET,
-                  MODE == M_ROLLOUT || MODE == M_INIT || MODE == M_SPLIT_INIT);   // 1-player: FIFO words stay as zeroed at creation
+                  MODE == M_ROLLOUT || MODE == M_INIT || MODE == M_SPLIT_INIT, MEM);   // 1-player: FIFO words stay as zeroed at creation
     report_status(a, g.status);
 }
 
@@ -290,7 +311,7 @@ TE_HD void split_body(const KArgs& a, int i, const uint32_t* shapes) {
     } else {
         const uint32_t opp_b = a.xw[(size_t)(side == 0 ? 3 : 2) * a.n + i];
         const int in = (side == 0 && !(opp_b & XW_DIED)) ? xw_sent(opp_b) : 0;
-        const int done = split_finish(g, in, (opp_b & XW_DEAD_NOW) != 0);
+        const int done = split_finish(g, in, (opp_b & XW_DEAD_NOW) != 0, (opp_b & XW_ERR) != 0);
         if (a.done) a.done[i] = (uint8_t)done;
         if (a.lines) a.lines[i] = (uint8_t)q.reward;
         if (a.dead) a.dead[i] = (uint8_t)q.dead;
@@ -397,7 +418,7 @@ TE_HD int observe_board(const Geo& geo, size_t slot, int p, int H, uint8_t* cell
 //             pre[x] & suf[x + 4] & (the four columns under the piece | its cells) — no pass over all ten columns
 // A placement lane then needs ~10 LDS reads and no loop over the board.
 constexpr int PRE_COL = 0, PRE_PIECE = 10, PRE_BAND = 11, PRE_STRIP = 13, PRE_PRE = 17, PRE_SUF = 28, PRE_WORDS = 40;
-constexpr int ENUM_BOARDS = 8, ENUM_BLOCK = ENUM_BOARDS * 40;      // boards / threads per workgroup of k_enumerate
+constexpr int ENUM_BOARDS = 32, ENUM_BLOCK = ENUM_BOARDS * 10;     // boards / threads per workgroup of k_enumerate (10 lanes per board)
 
 // element functions of the per-board precompute (lane j of a board calls the ones its index selects)
 TE_HD uint32_t pre_band_bits(uint32_t col, uint32_t floor_bits, int c, int& word) {      // nibble c+2 of the 64-bit band
@@ -523,20 +544,24 @@ TE_HD uint32_t enum_after_col(const uint32_t* pre, const Placement& pl, int c) {
     return pre[PRE_COL + c] | cells;
 }
 
-// serial driver of one placement (CPU harness): lane t = (game i, rotation r, column index xi)
-// `planar`: after[c][lanes] instead of after[lane][c]
+// serial driver of one board's 40 placements (CPU harness)
+// `planar`: rotation-major outputs, valid / land_y / cleared [4][n][10] and after [10][4][n][10] (see k_enumerate)
 template <int P>
-TE_HD void enumerate_body(const Geo& geo, size_t t, const int32_t* idx, const uint8_t* player, int H,
-                          const uint32_t* shapes, uint8_t* valid, int8_t* land_y, uint8_t* cleared, uint32_t* after, size_t lanes, bool planar) {
-    const int i = (int)(t / 40), j = (int)(t % 40), r = j / 10, xi = j % 10;
+TE_HD void enumerate_body(const Geo& geo, int i, int n, const int32_t* idx, const uint8_t* player, int H,
+                          const uint32_t* shapes, uint8_t* valid, int8_t* land_y, uint8_t* cleared, uint32_t* after, bool planar) {
     uint32_t pre[PRE_WORDS];
     enum_prepare(geo, safe_slot(idx, i, (int)geo.n_games), safe_player(player, i, P), H, pre);
-    const Placement pl = enum_place(pre, shapes, H, r, xi);
-    valid[t] = (uint8_t)pl.ok;
-    land_y[t] = (int8_t)pl.y;
-    cleared[t] = (uint8_t)pl.cleared;
-    if (after)
-        for (int c = 0; c < NCOL; c++) after[planar ? (size_t)c * lanes + t : t * NCOL + c] = enum_after_col(pre, pl, c);
+    for (int r = 0; r < 4; r++)
+        for (int xi = 0; xi < NCOL; xi++) {
+            const Placement pl = enum_place(pre, shapes, H, r, xi);
+            const size_t t = planar ? ((size_t)r * n + i) * 10 + xi : ((size_t)i * 4 + r) * 10 + xi;
+            valid[t] = (uint8_t)pl.ok;
+            land_y[t] = (int8_t)pl.y;
+            cleared[t] = (uint8_t)pl.cleared;
+            if (after)
+                for (int c = 0; c < NCOL; c++)
+                    after[planar ? ((size_t)c * 4 + r) * (size_t)n * 10 + (size_t)i * 10 + xi : t * NCOL + c] = enum_after_col(pre, pl, c);
+        }
 }
 
 // PythonHandle.cpp:190 get_actions -> TestField.cpp:64-111 getMask(2): lane t = (game i, rotation r, column xi);

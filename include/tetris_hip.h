@@ -20,7 +20,8 @@
  *    without synchronising (zero-copy callers, benchmarks); all others are synchronous.
  *    Host index / player arrays are validated (TETRIS_E_ARG); device-resident ones cannot be, so an
  *    out-of-range game index or player in a d_idx / d_player array is clamped into the batch by the kernel.
- *  - board height 4..31, width 10 (the reference hard-codes 10, gamePlay.cpp:202), 1 or 2 players.
+ *  - board height 4..31, width 10 (the reference hard-codes 10, gamePlay.cpp:202), 1 or 2 players (the reference takes
+ *    any n_players, PythonHandle.cpp:5-25; none of its presets or agents uses more than two).
  */
 #ifndef TETRIS_HIP_H
 #define TETRIS_HIP_H
@@ -34,8 +35,16 @@ extern "C" {
 #define TETRIS_OK 0
 #define TETRIS_E_ARG (-1)        /* bad argument */
 #define TETRIS_E_HIP (-2)        /* a HIP runtime call failed (no device, out of memory, ...) */
-#define TETRIS_E_STREAM (-3)     /* an episode outran the RNG tables (> 39 936 draws) */
-#define TETRIS_E_FIFO (-4)       /* more than 8 pending garbage packets on one board */
+#define TETRIS_E_STREAM (-3)     /* (no longer returned: see TETRIS_ERR_STREAM) */
+#define TETRIS_E_FIFO (-4)       /* (no longer returned: see TETRIS_ERR_FIFO) */
+
+/* Capacity errors are confined to the game they happen in.  The reference's garbage queue is an unbounded vector
+ * (Garbage.h:27) and its generators never run out (randomizer.h:44-50); here a board holds at most 8 pending garbage
+ * packets and an episode at most 39 936 piece draws.  A game that exceeds either ends its round in that step (`done`), its
+ * boards carry the bits below in tetris_record.fifo_overflow until the game is reset, and every other game of the batch
+ * goes on untouched.  tetris_take_errors tells whether any game of the batch was ended this way since the last call.   */
+#define TETRIS_ERR_FIFO 1u       /* a 9th garbage packet arrived while 8 were pending: it was dropped */
+#define TETRIS_ERR_STREAM 2u     /* the episode ran past the RNG tables: the pieces dealt in that step are wrong */
 
 #define TETRIS_MAX_H 32
 #define TETRIS_W 10
@@ -85,6 +94,7 @@ int tetris_create_ex(tetris_batch **out, int n_games, int n_players, int height,
                      const uint8_t piece_map[7], int device, const int16_t *seeds, int flags);
 int tetris_destroy(tetris_batch *b);
 int tetris_sync(tetris_batch *b);                      /* drain the stream, surface sticky errors */
+int tetris_take_errors(tetris_batch *b, uint32_t *bits);   /* synchronises; *bits = TETRIS_ERR_* seen since the last call, then cleared */
 
 /* replaces: PythonHandle.reset() with time(NULL) == seeds[i] (PythonHandle.cpp:49-71)           */
 int tetris_reset(tetris_batch *b, const int32_t *idx, int n, const int16_t *seeds);
@@ -165,10 +175,11 @@ int tetris_enumerate_drops(tetris_batch *b, const int32_t *idx, int n, const uin
 /* same with device pointers (d_idx / d_player may be NULL), asynchronous on the batch's stream                        */
 int tetris_enumerate_drops_dev(tetris_batch *b, const int32_t *d_idx, int n, const uint8_t *d_player,
                                uint8_t *d_valid, int8_t *d_land_y, uint8_t *d_cleared, uint32_t *d_after);
-/* same with flags.  TETRIS_ENUM_AFTER_PLANAR: d_after is [10][n*40] — column c of placement t at d_after[c * n*40 + t],
- * t = (game * 4 + r) * 10 + xi — instead of [n*40][10]: every store of a wavefront is then 256 contiguous bytes, and a
- * consumer that feeds the afterstates to a network reads one column plane at a time.                                 */
-#define TETRIS_ENUM_AFTER_PLANAR 1
+/* same with flags.  TETRIS_ENUM_PLANAR: every output is rotation-major — d_valid / d_land_y / d_cleared are [4][n][10] and
+ * d_after is [10][4][n][10] (column c of the placement (game i, rotation r, column index xi) at
+ * d_after[((c * 4 + r) * n + i) * 10 + xi]) — so that every store of a wavefront is 64 consecutive elements; a consumer
+ * that feeds the afterstates to a network reads one (column, rotation) plane at a time.                              */
+#define TETRIS_ENUM_PLANAR 1
 int tetris_enumerate_drops_dev_ex(tetris_batch *b, const int32_t *d_idx, int n, const uint8_t *d_player,
                                   uint8_t *d_valid, int8_t *d_land_y, uint8_t *d_cleared, uint32_t *d_after, int flags);
 

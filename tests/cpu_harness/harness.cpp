@@ -111,13 +111,8 @@ static void run(tetris_batch* b, const KArgs& a, LaneCounters* total = nullptr) 
 }
 
 static int finish_call(tetris_batch* b) {
-    if (b->flags[F_EXHAUSTED]) return fail(TETRIS_E_STREAM, "an episode ran past the RNG tables");
-    if (b->flags[F_FIFO]) return fail(TETRIS_E_FIFO, "garbage FIFO overflow");
     if (b->flags[F_EXTEND]) {
-        if (b->flags[F_EXTEND] >= (uint32_t)b->tab->n_chunks * CHUNK) {
-            if (b->tab->n_chunks >= MAX_CHUNKS) return fail(TETRIS_E_STREAM, "MAX_CHUNKS reached");
-            b->tab->extend();
-        }
+        if (b->flags[F_EXTEND] >= (uint32_t)b->tab->n_chunks * CHUNK && b->tab->n_chunks < MAX_CHUNKS) b->tab->extend();
         b->flags[F_EXTEND] = 0;
     }
     if (b->flags[F_BADARG]) { b->flags[F_BADARG] = 0; return fail(TETRIS_E_ARG, "output capacity exceeded"); }
@@ -246,6 +241,12 @@ int tetris_rollout_totals(tetris_batch* b, uint64_t totals[4]) {
 }
 int tetris_destroy(tetris_batch* b) { delete b; return TETRIS_OK; }
 int tetris_sync(tetris_batch* b) { return finish_call(b); }
+int tetris_take_errors(tetris_batch* b, uint32_t* bits) {
+    if (!bits) return fail(TETRIS_E_ARG, "bits is NULL");
+    *bits = (b->flags[F_FIFO] ? TETRIS_ERR_FIFO : 0u) | (b->flags[F_EXHAUSTED] ? TETRIS_ERR_STREAM : 0u);
+    b->flags[F_FIFO] = 0; b->flags[F_EXHAUSTED] = 0;
+    return TETRIS_OK;
+}
 int tetris_set_game_offset(tetris_batch* b, uint64_t first) { b->game_offset = (uint32_t)first; return TETRIS_OK; }
 
 static int check_idx(tetris_batch* b, const int32_t* idx, int n) {
@@ -352,11 +353,10 @@ int tetris_set_dead(tetris_batch* b, const int32_t* idx, int n, const uint8_t* d
 int tetris_enumerate_drops_dev_ex(tetris_batch* b, const int32_t* idx, int n, const uint8_t* player, uint8_t* valid, int8_t* land_y,
                                   uint8_t* cleared, uint32_t* after, int flags) {
     int rc = check_idx(b, idx, n); if (rc) return rc;
-    if (flags & ~TETRIS_ENUM_AFTER_PLANAR) return fail(TETRIS_E_ARG, "unknown flag");
-    const size_t lanes = (size_t)n * 40;
-    for (size_t t = 0; t < lanes; t++) {
-        if (b->P == 1) enumerate_body<1>(geo_of_batch(b), t, idx, player, b->H, SHAPES.s, valid, land_y, cleared, after, lanes, flags & TETRIS_ENUM_AFTER_PLANAR);
-        else enumerate_body<2>(geo_of_batch(b), t, idx, player, b->H, SHAPES.s, valid, land_y, cleared, after, lanes, flags & TETRIS_ENUM_AFTER_PLANAR);
+    if (flags & ~TETRIS_ENUM_PLANAR) return fail(TETRIS_E_ARG, "unknown flag");
+    for (int i = 0; i < n; i++) {
+        if (b->P == 1) enumerate_body<1>(geo_of_batch(b), i, n, idx, player, b->H, SHAPES.s, valid, land_y, cleared, after, flags & TETRIS_ENUM_PLANAR);
+        else enumerate_body<2>(geo_of_batch(b), i, n, idx, player, b->H, SHAPES.s, valid, land_y, cleared, after, flags & TETRIS_ENUM_PLANAR);
     }
     return TETRIS_OK;
 }
