@@ -381,8 +381,13 @@ __global__ __launch_bounds__(ENUM_BLOCK) void k_enumerate(Geo geo, int n, const 
     return;
 #endif
     const size_t boards = (size_t)n;
+    const ColumnCtx cc = enum_column(pre, j);
+    uint32_t board[NCOL];                                   // the board's columns, read once for the four afterstates
+    if (after)
+        for (int c = 0; c < NCOL; c++) board[c] = pre[PRE_COL + c];
+    TE_UNROLL
     for (int r = 0; r < 4; r++) {
-        const Placement pl = enum_place(pre, s_shapes, H, r, j);
+        const Placement pl = enum_place(pre, cc, s_shapes, H, r);
         const size_t t = PLANAR ? ((size_t)r * boards + i) * 10 + j : ((size_t)i * 4 + r) * 10 + j;
 #if defined(TE_ENUM_EXP) && TE_ENUM_EXP == 3
         if (pl.ok + pl.y + pl.cleared == 12345) valid[t] = 1;      // experiment: no byte stores
@@ -393,7 +398,7 @@ __global__ __launch_bounds__(ENUM_BLOCK) void k_enumerate(Geo geo, int n, const 
 #endif
         if (after) {
             for (int c = 0; c < NCOL; c++) {
-                const uint32_t v = enum_after_col(pre, pl, c);
+                const uint32_t v = enum_after_col(board[c], pl, c);
                 if (PLANAR) __builtin_nontemporal_store(v, &after[((size_t)c * 4 + r) * boards * 10 + (size_t)i * 10 + j]);
                 else after[t * NCOL + c] = v;             // 40 contiguous bytes per lane: left to the L2 to merge
             }
@@ -573,6 +578,8 @@ struct tetris_batch {
     uint32_t* d_chain = nullptr;
     uint32_t chain_epoch = 0;
     int use_chain = 1;                   // TETRIS_NO_CHAIN=1 in the environment: every rollout launch on the batch's one stream
+    bool chain_pending = false;          // chained launches were enqueued since the last drain
+    bool home_async = false;             // asynchronous (_dev) work was enqueued on the batch's stream since the last drain
     // Run-ahead gate of the asynchronous entry points: every GATE_GROUP launches an event is recorded; before a new group is
     // enqueued the host waits for the event of the group before the previous one.  At most 2 * GATE_GROUP + 1 launches are
     // therefore in flight whose flag words the host has not seen; `margin` is sized for that many steps.
@@ -656,12 +663,28 @@ static int gate_launch(tetris_batch* b, int group = GATE_GROUP) {
         b->gate_count = 0;
     }
     b->gate_count++;
+    if (b->stream != b->chain_stream[0] && b->stream != b->chain_stream[1]) b->home_async = true;
     return service_flags(b);
 }
 
-// drain the stream, then the flag words: sticky errors surface, the RNG tables are extended when a board came close to their end
+// Waits for a stream by polling it for a while before falling back to the blocking wait: a blocked host thread is woken
+// through an interrupt, 10-20 us after the GPU is done — as long as a whole 20-launch rollout of 64k boards.
+static hipError_t drain_stream(hipStream_t st) {
+    for (int spin = 0; spin < 20000; spin++) {
+        const hipError_t e = hipStreamQuery(st);
+        if (e != hipErrorNotReady) return e;
+    }
+    return hipStreamSynchronize(st);
+}
+
+// drain the batch's stream(s), then the flag words: sticky errors surface, the RNG tables are extended when a board came close to their end
 static int finish_call(tetris_batch* b) {
-    HIP_TRY(hipStreamSynchronize(b->stream));
+    if (b->chain_pending) {
+        for (int k = 0; k < 2; k++) HIP_TRY(drain_stream(b->chain_stream[k]));
+        b->chain_pending = false;
+    }
+    HIP_TRY(drain_stream(b->stream));
+    b->home_async = false;
     b->gate_count = 0; b->gate_pending[0] = b->gate_pending[1] = 0;
     volatile uint32_t* f = b->flags;
     // (F_EXHAUSTED / F_FIFO: capacity errors are confined to the games they happened in — tetris_take_errors)
@@ -878,6 +901,7 @@ int tetris_split_stage_dev(tetris_batch* b, int stage, const uint8_t* d_rot, con
     if (stage == 0 && (!d_rot || !d_trans)) return fail(TETRIS_E_ARG, "stage 0 needs rot/trans");
     if (stage < 2 && !d_out) return fail(TETRIS_E_ARG, "stages 0 and 1 need d_out");
     if (stage > 0 && !d_words) return fail(TETRIS_E_ARG, "stages 1 and 2 need d_words");
+    b->home_async = true;
     KArgs a = base_args(b, b->N, nullptr);
     a.rot = d_rot; a.trans = d_trans; a.player = d_acting; a.ms = ms;
     a.shadow = b->d_shadow; a.xw = d_words; a.xout = d_out; a.done = d_done; a.lines = d_lines; a.dead = d_dead;
@@ -897,6 +921,7 @@ int tetris_split_rollout_stage_dev(tetris_batch* b, int stage, uint32_t policy_s
     if (stage < 0 || stage > 2) return fail(TETRIS_E_ARG, "stage must be 0, 1 or 2");
     if (stage < 2 && !d_out) return fail(TETRIS_E_ARG, "stages 0 and 1 need d_out");
     if (stage > 0 && !d_words) return fail(TETRIS_E_ARG, "stages 1 and 2 need d_words");
+    b->home_async = true;
     KArgs a = base_args(b, b->N, nullptr);
     a.ms = ms; a.policy_seed = policy_seed; a.first_step = step; a.steps = 1;
     a.shadow = b->d_shadow; a.xw = d_words; a.xout = d_out;
@@ -1147,6 +1172,7 @@ int tetris_observe_packed_dev(tetris_batch* b, const int32_t* d_idx, int n, cons
     if (!d_visual || !d_vector || !d_piece) return fail(TETRIS_E_ARG, "visual/vector/piece are NULL");
     if (n < 0 || (!d_idx && n > b->N)) return fail(TETRIS_E_ARG, "n out of range");
     if (n == 0) return TETRIS_OK;
+    b->home_async = true;
     dim3 grid((unsigned)((n + 255) / 256)), block(256);
     if (b->H % 2 == 0 && ((uintptr_t)d_visual & 3u) == 0 && ((uintptr_t)d_vector & 3u) == 0) {
         // one wave per workgroup (<= 20 KB of LDS): several workgroups per CU overlap their load / build / store phases
@@ -1292,6 +1318,7 @@ int tetris_enumerate_drops_dev_ex(tetris_batch* b, const int32_t* d_idx, int n, 
     if (n < 0 || (!d_idx && n > b->N)) return fail(TETRIS_E_ARG, "n out of range");
     if (flags & ~TETRIS_ENUM_PLANAR) return fail(TETRIS_E_ARG, "unknown flag");
     if (n == 0) return TETRIS_OK;
+    b->home_async = true;
     dim3 grid((unsigned)((n + ENUM_BOARDS - 1) / ENUM_BOARDS)), block(ENUM_BLOCK);
     const Geo geo = geo_of_batch(b);
     const bool planar = (flags & TETRIS_ENUM_PLANAR) != 0;
@@ -1409,19 +1436,20 @@ int tetris_rollout_launch(tetris_batch* b, int launches, int steps_per_launch, u
     // single-player batches on their own stream: chained launches (k_chain) — consecutive launches alternate between two
     // streams and each wave waits for its own predecessor only, not for the slowest wave of the whole previous launch
     const bool chained = b->use_chain && b->P == 1 && !b->tint && !b->split && b->stream == b->own_stream && steps_per_launch >= 1;
-    HIP_TRY(hipEventRecord(b->ev0, b->stream));
-    if (chained) {
-        // both chain streams start behind everything the batch's stream has been given so far
-        HIP_TRY(hipEventRecord(b->chain_ev[2], b->stream));
+    hipStream_t const home = b->stream;
+    if (chained && b->home_async) {
+        // both chain streams start behind the asynchronous work the batch's stream still holds (after a synchronous call it
+        // is empty and nothing has to be ordered)
+        HIP_TRY(hipEventRecord(b->chain_ev[2], home));
         for (int k = 0; k < 2; k++) HIP_TRY(hipStreamWaitEvent(b->chain_stream[k], b->chain_ev[2], 0));
     }
-    hipStream_t const home = b->stream;
+    HIP_TRY(hipEventRecord(b->ev0, chained ? b->chain_stream[0] : home));
     struct StreamGuard {                          // base_args / launch_game / gate_launch work on b->stream
         tetris_batch* b; hipStream_t home;
         ~StreamGuard() { b->stream = home; }
     } stream_guard{b, home};
     for (int l = 0; l < launches; l++) {
-        if (chained) b->stream = b->chain_stream[l & 1];
+        if (chained) { b->stream = b->chain_stream[l & 1]; b->chain_pending = true; }
         if ((rc = gate_launch(b, group))) return rc;
         KArgs a = base_args(b, b->N, nullptr);
         a.ms = ms; a.steps = steps_per_launch; a.policy_seed = policy_seed;
@@ -1433,15 +1461,10 @@ int tetris_rollout_launch(tetris_batch* b, int launches, int steps_per_launch, u
         } else if ((rc = launch_game<M_ROLLOUT>(b, a)))
             return rc;
     }
-    b->stream = home;
-    if (chained) {                                // the batch's stream continues behind both chain streams
-        for (int k = 0; k < 2; k++) {
-            HIP_TRY(hipEventRecord(b->chain_ev[k], b->chain_stream[k]));
-            HIP_TRY(hipStreamWaitEvent(home, b->chain_ev[k], 0));
-        }
-    }
+    // the last launch ends after every wave of the launch before it has published its epoch: its stream carries the end event
     HIP_TRY(hipEventRecord(b->ev1, b->stream));
-    if ((rc = finish_call(b))) return rc;
+    b->stream = home;
+    if ((rc = finish_call(b))) return rc;         // drains both chain streams and the batch's own
     if (elapsed_ms) HIP_TRY(hipEventElapsedTime(elapsed_ms, b->ev0, b->ev1));
     return TETRIS_OK;
 }

@@ -455,45 +455,63 @@ TE_HD void enum_prepare(const Geo& geo, size_t slot, int p, int H, uint32_t* pre
     for (int i = 0; i <= NCOL; i++) { pre[PRE_PRE + i] = pre_and_below(pre + PRE_COL, i); pre[PRE_SUF + i] = pre_and_from(pre + PRE_COL, i); }
 }
 
-struct Placement { int ok, y, cleared; uint32_t cells[4]; int x; };     // cells[k] = the piece's squares in board column x + k
+// What the four rotations of one column index share (hoisted out of the rotation loop): the piece, the depths under its 4x4
+// box, the four board columns there and the AND of all the others.
+struct ColumnCtx {
+    int kind, cur_rot, n_rot, x;
+    unsigned xs;                     // x + 2: the piece's position in the band window
+    uint64_t band;                   // collision window of row 0
+    uint32_t under;                  // free depth of the four board columns under the box, a byte each (walls: 0)
+    uint32_t colk[4];                // board columns x .. x + 3 (all ones outside the board: neutral in the full-row AND)
+    uint32_t rest;                   // AND of the board's other columns
+};
+struct Placement { int ok, y, cleared; uint64_t placed; };      // placed: the shape's nibbles at the piece's band position
 
-// one placement against a prepared board (`pre` = its BoardPre; LDS on the GPU)
-TE_HD Placement enum_place(const uint32_t* pre, const uint32_t* shapes, int H, int r, int xi) {
+TE_HD ColumnCtx enum_column(const uint32_t* pre, int xi) {
+    ColumnCtx cc;
+    const uint32_t w = pre[PRE_PIECE];
+    cc.kind = w & 7; cc.cur_rot = (w >> 3) & 3;
+    cc.n_rot = cc.kind == 6 ? 1 : (cc.kind == 4 || cc.kind == 2 || cc.kind == 3) ? 2 : 4;     // TestField.cpp:71-109
+    cc.x = xi - 1;
+    cc.xs = (unsigned)(cc.x + 2);                                                            // 1..10
+    cc.band = ((uint64_t)pre[PRE_BAND + 1] << 32) | pre[PRE_BAND];
+    const uint32_t lo = pre[PRE_STRIP + (cc.xs >> 2)], hi = (cc.xs >> 2) < 3 ? pre[PRE_STRIP + (cc.xs >> 2) + 1] : 0u;
+#if defined(__HIP_DEVICE_COMPILE__)
+    cc.under = __builtin_amdgcn_alignbyte(hi, lo, cc.xs & 3u);
+#else
+    cc.under = (uint32_t)((((uint64_t)hi << 32) | lo) >> (8 * (cc.xs & 3u)));
+#endif
+    for (int k = 0; k < 4; k++) {
+        const int c = cc.x + k;
+        cc.colk[k] = (c >= 0 && c < NCOL) ? pre[PRE_COL + c] : ~0u;
+    }
+    cc.rest = pre[PRE_PRE + imax(0, imin(NCOL, cc.x))] & pre[PRE_SUF + imax(0, imin(NCOL, cc.x + 4))];
+    return cc;
+}
+
+// one placement (rotation r of the lane's column) against a prepared board (`pre` = its BoardPre; LDS on the GPU)
+TE_HD Placement enum_place(const uint32_t* pre, const ColumnCtx& cc, const uint32_t* shapes, int H, int r) {
     Placement out;
     const uint32_t floor_bits = ~0u << H;
-    const uint32_t w = pre[PRE_PIECE];
-    const int kind = w & 7, cur_rot = (w >> 3) & 3;
-    const int n_rot = kind == 6 ? 1 : (kind == 4 || kind == 2 || kind == 3) ? 2 : 4;     // TestField.cpp:71-109
-    const int rot = kind == 6 ? cur_rot : r;                                               // O is used as it stands
-    const uint32_t shape = shapes[((kind & 7) << 2) | rot], nibs = shape & 0xFFFFu;
-    const int x = xi - 1;
-    const unsigned xs = (unsigned)(x + 2);                                                 // 1..10
-    const uint64_t band = ((uint64_t)pre[PRE_BAND + 1] << 32) | pre[PRE_BAND];
-    out.x = x;
-    out.ok = kind <= 6 && r < n_rot && x <= NCOL - 2 && (((uint64_t)nibs << (4 * xs)) & band) == 0;   // gameField.cpp:10-20 at (x, 0)
+    const int rot = cc.kind == 6 ? cc.cur_rot : r;                                         // O is used as it stands
+    const uint32_t nibs = shapes[((cc.kind & 7) << 2) | rot] & 0xFFFFu;
+    out.placed = (uint64_t)nibs << (4 * cc.xs);
+    out.ok = cc.kind <= 6 && r < cc.n_rot && cc.x <= NCOL - 2 && (out.placed & cc.band) == 0;   // gameField.cpp:10-20 at (x, 0)
     out.y = 0; out.cleared = 0;
-    for (int k = 0; k < 4; k++) out.cells[k] = 0;
-    if (!out.ok) return out;
+    if (!out.ok) { out.placed = 0; return out; }
     // hard drop (gameField.cpp:49-53): the four depths under the piece + the shape's drop word, byte minimum
-    const uint32_t lo = pre[PRE_STRIP + (xs >> 2)], hi = (xs >> 2) < 3 ? pre[PRE_STRIP + (xs >> 2) + 1] : 0u;
-#if defined(__HIP_DEVICE_COMPILE__)
-    const uint32_t under = __builtin_amdgcn_alignbyte(hi, lo, xs & 3u);
-#else
-    const uint32_t under = (uint32_t)((((uint64_t)hi << 32) | lo) >> (8 * (xs & 3u)));
-#endif
-    const uint32_t sum = under + shapes[32 + (((kind & 7) << 2) | rot)];
+    const uint32_t sum = cc.under + shapes[32 + (((cc.kind & 7) << 2) | rot)];
     const uint32_t b0 = sum & 0xFFu, b1 = (sum >> 8) & 0xFFu, b2 = (sum >> 16) & 0xFFu, b3 = sum >> 24;
     const uint32_t m01 = b0 < b1 ? b0 : b1, m23 = b2 < b3 ? b2 : b3;
-    uint32_t m = m01 < m23 ? m01 : m23;
+    const uint32_t m = m01 < m23 ? m01 : m23;
     int y;
     if (m - 0x40u > 0x3Eu) {          // an obstacle above a piece column's top cell inside the 4x4 box: exact closed form per column
         int dist = 64;
         for (int gx = 0; gx < 4; gx++) {
             const uint32_t nib = (nibs >> (4 * gx)) & 0xFu;
-            const int c = x + gx;
-            if (nib && c >= 0 && c < NCOL) {
+            if (nib) {                // (an occupied piece column of a piece that fits lies inside the board)
                 const int top = ctz32(nib), bottom = 31 - clz32(nib);
-                const uint32_t below = (pre[PRE_COL + c] | floor_bits) >> (top + 1);
+                const uint32_t below = (cc.colk[gx] | floor_bits) >> (top + 1);
                 const int first = below ? ctz32(below) + top + 1 : 32;
                 dist = imin(dist, imax(0, first - bottom - 1));
             }
@@ -503,22 +521,14 @@ TE_HD Placement enum_place(const uint32_t* pre, const uint32_t* shapes, int H, i
         y = (int)(m - 0x40u);
     out.y = y;
     // stamp (gameField.cpp:105-110) and the rows a finalize would clear (gameField.cpp:120-145)
-    const int lo_c = imax(0, imin(NCOL, x)), hi_c = imax(0, imin(NCOL, x + 4));
-    uint32_t full = pre[PRE_PRE + lo_c] & pre[PRE_SUF + hi_c];
-    for (int k = 0; k < 4; k++) {
-        const int c = x + k;
-        const uint32_t cells = ((nibs >> (4 * k)) & 0xFu) << y;
-        const bool inside = c >= 0 && c < NCOL;
-        out.cells[k] = inside ? cells : 0u;
-        if (inside) full &= pre[PRE_COL + c] | cells;
-    }
+    uint32_t full = cc.rest;
+    for (int k = 0; k < 4; k++) full &= cc.colk[k] | (((nibs >> (4 * k)) & 0xFu) << y);
     const uint32_t range = (~0u << y) & ~floor_bits;
     if (full & ~range & ~floor_bits) {
         // a full row ABOVE the piece (unreachable by play; only a crafted restore could hold one): the reference re-scans rows
         // that shift into range, so count exactly like clear_rows
         uint32_t colv[NCOL];
-        for (int c = 0; c < NCOL; c++) colv[c] = pre[PRE_COL + c];
-        for (int k = 0; k < 4; k++) { const int c = x + k; if (c >= 0 && c < NCOL) for (int cc = 0; cc < NCOL; cc++) if (cc == c) colv[cc] |= out.cells[k]; }
+        for (int c = 0; c < NCOL; c++) colv[c] = pre[PRE_COL + c] | (((uint32_t)(out.placed >> (4 * c + 8)) & 0xFu) << y);
         int cleared = 0;
         for (;;) {
             uint32_t f = range;
@@ -535,13 +545,9 @@ TE_HD Placement enum_place(const uint32_t* pre, const uint32_t* shapes, int H, i
     return out;
 }
 
-// column c of the stamped board of a placement
-TE_HD uint32_t enum_after_col(const uint32_t* pre, const Placement& pl, int c) {
-    const int k = c - pl.x;
-    uint32_t cells = 0;
-    cells = k == 0 ? pl.cells[0] : cells; cells = k == 1 ? pl.cells[1] : cells;
-    cells = k == 2 ? pl.cells[2] : cells; cells = k == 3 ? pl.cells[3] : cells;
-    return pre[PRE_COL + c] | cells;
+// column c (a compile-time constant after unrolling) of the stamped board of a placement: nibble c + 2 of `placed`, at row y
+TE_HD uint32_t enum_after_col(uint32_t board_col, const Placement& pl, int c) {
+    return board_col | (((uint32_t)(pl.placed >> (4 * c + 8)) & 0xFu) << pl.y);
 }
 
 // serial driver of one board's 40 placements (CPU harness)
@@ -553,14 +559,14 @@ TE_HD void enumerate_body(const Geo& geo, int i, int n, const int32_t* idx, cons
     enum_prepare(geo, safe_slot(idx, i, (int)geo.n_games), safe_player(player, i, P), H, pre);
     for (int r = 0; r < 4; r++)
         for (int xi = 0; xi < NCOL; xi++) {
-            const Placement pl = enum_place(pre, shapes, H, r, xi);
+            const Placement pl = enum_place(pre, enum_column(pre, xi), shapes, H, r);
             const size_t t = planar ? ((size_t)r * n + i) * 10 + xi : ((size_t)i * 4 + r) * 10 + xi;
             valid[t] = (uint8_t)pl.ok;
             land_y[t] = (int8_t)pl.y;
             cleared[t] = (uint8_t)pl.cleared;
             if (after)
                 for (int c = 0; c < NCOL; c++)
-                    after[planar ? ((size_t)c * 4 + r) * (size_t)n * 10 + (size_t)i * 10 + xi : t * NCOL + c] = enum_after_col(pre, pl, c);
+                    after[planar ? ((size_t)c * 4 + r) * (size_t)n * 10 + (size_t)i * 10 + xi : t * NCOL + c] = enum_after_col(pre[PRE_COL + c], pl, c);
         }
 }
 
