@@ -55,6 +55,7 @@ _SIGNATURES = {
     "tetris_sync": (C.c_int, [C.c_void_p]),
     "tetris_take_errors": (C.c_int, [C.c_void_p, C.c_void_p]),
     "tetris_set_game_offset": (C.c_int, [C.c_void_p, C.c_uint64]),
+    "tetris_set_chained": (C.c_int, [C.c_void_p, C.c_int]),
     "tetris_reset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "tetris_make_actions": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
     "tetris_finish_actions": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -325,8 +326,14 @@ class TetrisBatch:
                                                    int(ms), _p(counters), C.byref(elapsed)))
         return counters, float(elapsed.value)
 
+    @staticmethod
+    def split_words(my_a=None, opp_a=None, b0=None, b1=None):
+        """The four exchange-word buffers of a split-mode step as the C array the stage calls take: raw device addresses
+        (int) of uint32 [n] — my A words, the opponent's A words, player 0's B words, player 1's B words — or None."""
+        return (C.c_void_p * 4)(*[C.c_void_p(int(p)) if p else C.c_void_p(0) for p in (my_a, opp_a, b0, b1)])
+
     def split_stage(self, stage, rot=None, trans=None, acting=None, words=None, out=None, done=None, lines=None, dead=None, ms=400):
-        """One stage of a split-mode step; every argument is a raw device address (int) or None."""
+        """One stage of a split-mode step; `words` = split_words(...), every other argument a raw device address (int) or None."""
         self._check(self.lib.tetris_split_stage_dev(self._h, int(stage), rot, trans, acting, int(ms), words, out, done, lines, dead))
 
     def split_rollout_stage(self, stage, step, words=None, out=None, policy_seed=0xD71, ms=400):
@@ -349,6 +356,10 @@ class TetrisBatch:
     def set_stream(self, stream_ptr, external=True):
         """Run on a caller-owned HIP stream (handle as int; 0 = the legacy default stream).  external=False: own stream."""
         self._check(self.lib.tetris_set_stream(self._h, C.c_void_p(int(stream_ptr) if stream_ptr else 0), 1 if external else 0))
+
+    def set_chained(self, on):
+        """Chained launches of the built-in rollout on / off (include/tetris_hip.h: tetris_set_chained)."""
+        self._check(self.lib.tetris_set_chained(self._h, 1 if on else 0))
 
     def set_game_offset(self, first_game_id):
         self._check(self.lib.tetris_set_game_offset(self._h, int(first_game_id)))

@@ -292,13 +292,14 @@ TE_HD void load_game_words(const Ref& gr, Game<P>& g, bool counters = false, int
 }
 
 template <int P>
-TE_HD void load_game(const Geo& geo_in, size_t slot, Game<P>& g, bool tint = false, bool queue = true, bool counters = false, int mem = MEM_STREAM) {
+TE_HD void load_game(const Geo& geo_in, size_t slot, Game<P>& g, bool tint = false, bool queue = true, bool counters = false, int mem = MEM_STREAM,
+                     bool uniform = false) {
     Geo geo = geo_in;
     geo.P = P;                           // compile-time stride factor for the hot loads
-    load_game_words<P>(game_ref(geo, slot), g, counters, mem);
+    load_game_words<P>(game_ref(geo, slot, uniform), g, counters, mem);
     TE_UNROLL
     for (int p = 0; p < P; p++) {
-        const Ref r = board_ref(geo, p, slot);
+        const Ref r = board_ref(geo, p, slot, uniform);
         load_player(r.s, r.o, r.ws, g.pl[p], tint, queue, mem);
     }
 }
@@ -348,13 +349,14 @@ TE_HD void store_game_words(const Ref& gr, const Game<P>& g, bool counters = fal
 }
 
 template <int P>
-TE_HD void store_game(const Geo& geo_in, size_t slot, const Game<P>& g, bool tint = false, bool queue = true, bool counters = false, int mem = MEM_STREAM) {
+TE_HD void store_game(const Geo& geo_in, size_t slot, const Game<P>& g, bool tint = false, bool queue = true, bool counters = false, int mem = MEM_STREAM,
+                      bool uniform = false) {
     Geo geo = geo_in;
     geo.P = P;
-    store_game_words<P>(game_ref(geo, slot), g, counters, mem);
+    store_game_words<P>(game_ref(geo, slot, uniform), g, counters, mem);
     TE_UNROLL
     for (int p = 0; p < P; p++) {
-        const Ref r = board_ref(geo, p, slot);
+        const Ref r = board_ref(geo, p, slot, uniform);
         store_player(r.s, r.o, r.ws, g.pl[p], tint, queue, mem);
     }
 }

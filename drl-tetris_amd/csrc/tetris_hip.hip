@@ -61,12 +61,16 @@ __global__ __launch_bounds__(256) void k_game(KArgs a) {
 // load / store is agent-scope (`sc1`: written through, read past the per-XCD L2), the storing wave drains its stores
 // (`s_waitcnt vmcnt(0)`) before it publishes — the measured-valid hand-off of MI355X_MICROARCH.md.  Spins are bounded: a wave
 // that gives up poisons its epoch word, raises F_CHAIN and leaves its games untouched, and the host reports an error.
+#ifndef TE_CHAIN_LANES
+#define TE_CHAIN_LANES 64          // games per wave of k_chain (experiment knob: 32 / 16 = emptier waves, more of them per SIMD)
+#endif
+constexpr int CHAIN_LANES = TE_CHAIN_LANES;
 template <int P>
 __global__ __launch_bounds__(64) void k_chain(KArgs a) {
     __shared__ __attribute__((aligned(16))) uint32_t s_shapes[SHAPE_WORDS];
     const int lane = threadIdx.x, wave = blockIdx.x;
-    const int i = wave * 64 + lane;
-    const bool active = i < a.n;
+    const int i = wave * CHAIN_LANES + lane;
+    const bool active = lane < CHAIN_LANES && i < a.n;
     LaneCounters cnt = {0, 0, 0, 0};
     const uint32_t shape_word = d_shape_table.s[lane];
     Game<P> g;
@@ -77,7 +81,7 @@ __global__ __launch_bounds__(64) void k_chain(KArgs a) {
         if (lane == 0) { ((volatile uint32_t*)a.status)[F_CHAIN] = 1u; st_agent(a.chain + wave, CHAIN_POISON); }
         return;
     }
-    if (active) { load_game<P>(geo_of(a), (size_t)i, g, false, P > 1, true, MEM_AGENT); g.draw0 = d0; g.draw1 = d1; }
+    if (active) { load_game<P>(geo_of(a), (size_t)i, g, false, P > 1, true, MEM_AGENT, CHAIN_LANES == 64); g.draw0 = d0; g.draw1 = d1; }
     s_shapes[lane] = shape_word;
     __builtin_amdgcn_wave_barrier();
     if (active) game_run<P, M_ROLLOUT, false, MEM_AGENT>(a, i, s_shapes, g, cnt);
@@ -119,7 +123,7 @@ __global__ __launch_bounds__(256) void k_duo(KArgs a) {
     constexpr bool ROLL = MODE == M_ROLLOUT, AUTO = MODE == M_STEP_RT_AUTO;
     Geo geo = geo_of(a);
     geo.P = 2;                           // compile-time stride factor for the hot loads
-    const Ref gr = game_ref(geo, (size_t)gi), br = board_ref(geo, side, (size_t)gi);
+    const Ref gr = game_ref(geo, (size_t)gi, true), br = board_ref(geo, side, (size_t)gi);     // the wave's 32 games lie in one tile
     Game<1> g;
     Player& q = g.pl[0];
     if (active) {
@@ -399,7 +403,11 @@ __global__ __launch_bounds__(ENUM_BLOCK) void k_enumerate(Geo geo, int n, const 
         if (after) {
             for (int c = 0; c < NCOL; c++) {
                 const uint32_t v = enum_after_col(board[c], pl, c);
+#if defined(TE_ENUM_PLAIN)
+                if (PLANAR) after[((size_t)c * 4 + r) * boards * 10 + (size_t)i * 10 + j] = v;
+#else
                 if (PLANAR) __builtin_nontemporal_store(v, &after[((size_t)c * 4 + r) * boards * 10 + (size_t)i * 10 + j]);
+#endif
                 else after[t * NCOL + c] = v;             // 40 contiguous bytes per lane: left to the L2 to merge
             }
         }
@@ -557,6 +565,7 @@ struct Stage {
 
 struct tetris_batch {
     int device = 0, N = 0, P = 0, H = 0;
+    int stride = 0;                      // games per row of the state arrays: N + padding (see create_impl)
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     uint32_t* d_state = nullptr;
@@ -592,21 +601,21 @@ struct tetris_batch {
 static constexpr int GATE_GROUP = 32;
 
 static Geo geo_of_batch(tetris_batch* b) {
-    Geo g = {b->d_state, b->d_gstate, (size_t)b->N, b->P, b->nw};
+    Geo g = {b->d_state, b->d_gstate ? b->d_gstate : b->d_state, (size_t)b->N, b->P, b->nw, (size_t)b->stride};
     return g;
 }
 
 static KArgs base_args(tetris_batch* b, int n, const int32_t* d_idx) {
     KArgs a;
     memset(&a, 0, sizeof a);
-    a.state = b->d_state; a.gstate = b->d_gstate; a.status = b->flags;
+    a.state = b->d_state; a.gstate = b->d_gstate ? b->d_gstate : b->d_state; a.status = b->flags;      // (tiled layout: one allocation)
     {   // tables are shared between batches: take pointer and size together (another batch may be growing them)
         std::lock_guard<std::mutex> lock(g_tab_mutex);
         a.table = b->tab->d_table;
         a.n_draws = (uint32_t)b->tab->n_chunks * CHUNK;
     }
     a.start = b->tab->d_start; a.combo_pow = b->tab->d_pow; a.margin = b->margin;
-    a.H = b->H; a.n_games = b->N; a.n_players = b->P; a.nw = b->nw; a.n = n; a.idx = d_idx; a.game_offset = b->game_offset;
+    a.H = b->H; a.n_games = b->N; a.n_stride = b->stride; a.n_players = b->P; a.nw = b->nw; a.n = n; a.idx = d_idx; a.game_offset = b->game_offset;
     return a;
 }
 
@@ -789,7 +798,7 @@ static int create_impl(tetris_batch** out, int n_games, int n_players, int heigh
     *out = nullptr;
     if (n_games < 1) return fail(TETRIS_E_ARG, "n_games must be >= 1");
     if (n_players != 1 && n_players != 2) return fail(TETRIS_E_ARG, "n_players must be 1 or 2");
-    if ((long long)n_games * n_players > (1ll << 30))       // one row of a state word stays below 4 GiB (32-bit lane offsets)
+    if (((long long)n_games + 4096) * n_players > (1ll << 30))       // one row of a state word stays below 4 GiB (32-bit lane offsets)
         return fail(TETRIS_E_ARG, "n_games * n_players must be <= 2^30");
     if (height < 4 || height > MAX_H) return fail(TETRIS_E_ARG, "height must be in [4, 31]");
     if (width != NCOL) return fail(TETRIS_E_ARG, "width must be 10 (the reference hard-codes 10, gamePlay.cpp:202)");
@@ -806,6 +815,7 @@ static int create_impl(tetris_batch** out, int n_games, int n_players, int heigh
     tetris_batch* b = new (std::nothrow) tetris_batch();
     if (!b) return fail(TETRIS_E_HIP, "out of host memory");
     b->device = device; b->N = n_games; b->P = n_players; b->H = height;
+    b->stride = n_games;
     b->tint = (flags & TETRIS_FLAG_COLOURS) ? 1 : 0;
     { const char* e = getenv("TETRIS_NO_DUO"); b->use_duo = !(e && e[0] == '1'); }
     { const char* e = getenv("TETRIS_NO_CHAIN"); b->use_chain = !(e && e[0] == '1'); }
@@ -825,21 +835,21 @@ static int create_impl(tetris_batch** out, int n_games, int n_players, int heigh
     for (int k = 0; k < 2; k++) CREATE_TRY(hipStreamCreateWithFlags(&b->chain_stream[k], hipStreamNonBlocking));
     for (int k = 0; k < 3; k++) CREATE_TRY(hipEventCreateWithFlags(&b->chain_ev[k], hipEventDisableTiming));
     {
-        const size_t chain_bytes = (((size_t)n_games + 63) / 64) * sizeof(uint32_t);
+        const size_t chain_bytes = (((size_t)n_games + CHAIN_LANES - 1) / CHAIN_LANES) * sizeof(uint32_t);
         CREATE_TRY(hipMalloc((void**)&b->d_chain, chain_bytes));
         CREATE_TRY(hipMemsetAsync(b->d_chain, 0, chain_bytes, b->stream));
     }
     CREATE_TRY(hipEventCreateWithFlags(&b->gate_ev[0], hipEventDisableTiming));
     CREATE_TRY(hipEventCreateWithFlags(&b->gate_ev[1], hipEventDisableTiming));
-    const size_t state_bytes = state_words((size_t)n_games, n_players, b->nw) * 4, gstate_bytes = gstate_words((size_t)n_games) * 4;
+    const size_t state_bytes = state_words((size_t)b->stride, n_players, b->nw) * 4, gstate_bytes = gstate_words((size_t)b->stride) * 4;
     CREATE_TRY(hipMalloc((void**)&b->d_state, state_bytes));
-    CREATE_TRY(hipMalloc((void**)&b->d_gstate, gstate_bytes));
+    if (gstate_bytes) CREATE_TRY(hipMalloc((void**)&b->d_gstate, gstate_bytes));
     CREATE_TRY(hipMalloc((void**)&b->d_counters, 8 * sizeof(unsigned long long)));
     CREATE_TRY(hipHostMalloc((void**)&b->h_counters, 8 * sizeof(unsigned long long), hipHostMallocDefault));
     // flag words: host memory the GPU can write (fine-grained, so a store is visible to the host while the kernel runs)
     CREATE_TRY(hipHostMalloc((void**)&b->flags, NFLAGS * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent));
     memset(b->flags, 0, NFLAGS * sizeof(uint32_t));
-    CREATE_TRY(hipMemsetAsync(b->d_gstate, 0, gstate_bytes, b->stream));
+    if (gstate_bytes) CREATE_TRY(hipMemsetAsync(b->d_gstate, 0, gstate_bytes, b->stream));
     CREATE_TRY(hipMemsetAsync(b->d_state, 0, state_bytes, b->stream));
     int rc = tables_acquire(&b->tab, device, piece_map, b->stream);
     if (rc) { std::string keep = g_err; tetris_destroy(b); return fail(rc, keep); }
@@ -858,6 +868,14 @@ static int create_impl(tetris_batch** out, int n_games, int n_players, int heigh
     if (!rc) rc = finish_call(b);
     if (rc) { std::string keep = g_err; tetris_destroy(b); return fail(rc, keep); }
     *out = b;
+    return TETRIS_OK;
+}
+
+int tetris_set_chained(tetris_batch* b, int on) {
+    int rc = check_batch(b);
+    if (rc) return rc;
+    if ((rc = finish_call(b))) return rc;
+    b->use_chain = on ? 1 : 0;
     return TETRIS_OK;
 }
 
@@ -892,19 +910,17 @@ int tetris_set_stream(tetris_batch* b, void* hip_stream, int external) {
     return TETRIS_OK;
 }
 
-int tetris_split_stage_dev(tetris_batch* b, int stage, const uint8_t* d_rot, const uint8_t* d_trans, const uint8_t* d_acting, int ms,
-                           const uint32_t* d_words, uint32_t* d_out, uint8_t* d_done, uint8_t* d_lines, uint8_t* d_dead) {
-    int rc = check_batch(b);
-    if (rc) return rc;
+static int split_stage_launch(tetris_batch* b, int stage, KArgs& a, const uint32_t* const d_words[4], uint32_t* d_out) {
     if (!b->split) return fail(TETRIS_E_ARG, "not a split batch (tetris_create_split)");
     if (stage < 0 || stage > 2) return fail(TETRIS_E_ARG, "stage must be 0, 1 or 2");
-    if (stage == 0 && (!d_rot || !d_trans)) return fail(TETRIS_E_ARG, "stage 0 needs rot/trans");
     if (stage < 2 && !d_out) return fail(TETRIS_E_ARG, "stages 0 and 1 need d_out");
+    // words a stage reads: stage 1 = both A words (+ player 0's B on side 1); stage 2 = the opponent's B
     if (stage > 0 && !d_words) return fail(TETRIS_E_ARG, "stages 1 and 2 need d_words");
+    if (stage == 1 && (!d_words[0] || !d_words[1] || (b->side == 1 && !d_words[2]))) return fail(TETRIS_E_ARG, "stage 1 needs both A words (and player 0's B words on side 1)");
+    if (stage == 2 && !d_words[b->side == 0 ? 3 : 2]) return fail(TETRIS_E_ARG, "stage 2 needs the opponent's B words");
     b->home_async = true;
-    KArgs a = base_args(b, b->N, nullptr);
-    a.rot = d_rot; a.trans = d_trans; a.player = d_acting; a.ms = ms;
-    a.shadow = b->d_shadow; a.xw = d_words; a.xout = d_out; a.done = d_done; a.lines = d_lines; a.dead = d_dead;
+    for (int k = 0; k < 4; k++) a.xw[k] = d_words ? d_words[k] : nullptr;
+    a.shadow = b->d_shadow; a.xout = d_out;
     dim3 grid((unsigned)((b->N + 255) / 256)), block(256);
     if (stage == 0) hipLaunchKernelGGL((k_split<0, false>), grid, block, 0, b->stream, a);
     else if (stage == 1) hipLaunchKernelGGL((k_split<1, false>), grid, block, 0, b->stream, a);
@@ -913,24 +929,24 @@ int tetris_split_stage_dev(tetris_batch* b, int stage, const uint8_t* d_rot, con
     return TETRIS_OK;
 }
 
-int tetris_split_rollout_stage_dev(tetris_batch* b, int stage, uint32_t policy_seed, uint64_t step, int ms, const uint32_t* d_words,
+int tetris_split_stage_dev(tetris_batch* b, int stage, const uint8_t* d_rot, const uint8_t* d_trans, const uint8_t* d_acting, int ms,
+                           const uint32_t* const d_words[4], uint32_t* d_out, uint8_t* d_done, uint8_t* d_lines, uint8_t* d_dead) {
+    int rc = check_batch(b);
+    if (rc) return rc;
+    if (stage == 0 && (!d_rot || !d_trans)) return fail(TETRIS_E_ARG, "stage 0 needs rot/trans");
+    KArgs a = base_args(b, b->N, nullptr);
+    a.rot = d_rot; a.trans = d_trans; a.player = d_acting; a.ms = ms;
+    a.done = d_done; a.lines = d_lines; a.dead = d_dead;
+    return split_stage_launch(b, stage, a, d_words, d_out);
+}
+
+int tetris_split_rollout_stage_dev(tetris_batch* b, int stage, uint32_t policy_seed, uint64_t step, int ms, const uint32_t* const d_words[4],
                                    uint32_t* d_out) {
     int rc = check_batch(b);
     if (rc) return rc;
-    if (!b->split) return fail(TETRIS_E_ARG, "not a split batch (tetris_create_split)");
-    if (stage < 0 || stage > 2) return fail(TETRIS_E_ARG, "stage must be 0, 1 or 2");
-    if (stage < 2 && !d_out) return fail(TETRIS_E_ARG, "stages 0 and 1 need d_out");
-    if (stage > 0 && !d_words) return fail(TETRIS_E_ARG, "stages 1 and 2 need d_words");
-    b->home_async = true;
     KArgs a = base_args(b, b->N, nullptr);
     a.ms = ms; a.policy_seed = policy_seed; a.first_step = step; a.steps = 1;
-    a.shadow = b->d_shadow; a.xw = d_words; a.xout = d_out;
-    dim3 grid((unsigned)((b->N + 255) / 256)), block(256);
-    if (stage == 0) hipLaunchKernelGGL((k_split<0, false>), grid, block, 0, b->stream, a);
-    else if (stage == 1) hipLaunchKernelGGL((k_split<1, false>), grid, block, 0, b->stream, a);
-    else hipLaunchKernelGGL((k_split<2, false>), grid, block, 0, b->stream, a);
-    HIP_TRY(hipGetLastError());
-    return TETRIS_OK;
+    return split_stage_launch(b, stage, a, d_words, d_out);
 }
 
 int tetris_rollout_totals(tetris_batch* b, uint64_t totals[4]) {
@@ -1456,7 +1472,7 @@ int tetris_rollout_launch(tetris_batch* b, int launches, int steps_per_launch, u
         a.first_step = first_step + (uint64_t)l * (uint64_t)steps_per_launch;
         if (chained) {
             a.chain = b->d_chain; a.epoch = ++b->chain_epoch;
-            hipLaunchKernelGGL((k_chain<1>), dim3((unsigned)((b->N + 63) / 64)), dim3(64), 0, b->stream, a);
+            hipLaunchKernelGGL((k_chain<1>), dim3((unsigned)((b->N + CHAIN_LANES - 1) / CHAIN_LANES)), dim3(64), 0, b->stream, a);
             HIP_TRY(hipGetLastError());
         } else if ((rc = launch_game<M_ROLLOUT>(b, a)))
             return rc;

@@ -19,7 +19,8 @@ struct KArgs {
     const double* combo_pow;
     uint32_t n_draws, margin;
     int H;
-    int n_games;              // N (stride of the SoA arrays)
+    int n_games;              // N
+    int n_stride;             // games per row of the state arrays (>= N)
     int n_players;            // P
     int nw;                   // words per player-board (NWORDS, or NWORDS_TINT with colour planes)
     int n;                    // lanes with work
@@ -44,7 +45,8 @@ struct KArgs {
     uint32_t* chain;          // chained launches: one epoch word per wave (NULL = launches are ordered by the stream)
     uint32_t epoch;           // chained launches: this launch's number; its waves wait for epoch - 1 and publish epoch
     uint32_t* shadow;         // split mode, side 1: post-settle state of the speculative loop-1 pass
-    const uint32_t* xw;       // split mode: exchange words [4][n]: my A, opponent's A, player 0's B, player 1's B
+    const uint32_t* xw[4];    // split mode: exchange words [n] each: my A, the opponent's A, player 0's B, player 1's B (separate buffers:
+                              // the words a kernel wrote and the rows an all-gather delivered are read where they lie, no copies)
     uint32_t* xout;           // split mode: this stage's word per board [n]
 };
 
@@ -68,7 +70,7 @@ TE_HD int safe_player(const uint8_t* player, int i, int P) { return safe_player_
 TE_HD bool lane_active(const KArgs& a, int i) { return i < a.n && (!a.mask || a.mask[i] != 0); }
 
 TE_HD Geo geo_of(const KArgs& a, uint32_t* state = nullptr) {
-    Geo g = {state ? state : a.state, a.gstate, (size_t)a.n_games, a.n_players, a.nw};
+    Geo g = {state ? state : a.state, a.gstate, (size_t)a.n_games, a.n_players, a.nw, (size_t)a.n_stride};
     return g;
 }
 
@@ -166,7 +168,7 @@ template <int P, int MODE, bool TINT = false, int MEM = MEM_STREAM>
 TE_HD void game_load(const KArgs& a, int i, Game<P>& g) {
     const size_t slot = a.idx ? (size_t)a.idx[i] : (size_t)i;
     if (MODE != M_INIT && MODE != M_SPLIT_INIT)
-        load_game<P>(geo_of(a), slot, g, TINT, P > 1 || MODE == M_SPLIT_RESET, MODE == M_ROLLOUT, MEM);   // split batches: 1-player layout WITH a queue
+        load_game<P>(geo_of(a), slot, g, TINT, P > 1 || MODE == M_SPLIT_RESET, MODE == M_ROLLOUT, MEM, !a.idx);   // split batches: 1-player layout WITH a queue
     // the first step's draw depends on kernel arguments only: its 40 dependent multiplies run while the state loads are in flight
     if (MODE == M_ROLLOUT) policy_draw(a, (uint32_t)slot, a.first_step, g.draw0, g.draw1);
     // (r, t) actions: the three action bytes are requested together with the state, not after it has arrived
@@ -256,7 +258,7 @@ TE_HD void game_run(const KArgs& a, int i, const uint32_t* shapes, Game<P>& g, L
         }
     }
     store_game<P>(geo_of(a), slot, g, TINT, P > 1 || MODE == M_SPLIT_INIT || MODE == M_SPLIT_RESET,
-                  MODE == M_ROLLOUT || MODE == M_INIT || MODE == M_SPLIT_INIT, MEM);   // 1-player: FIFO words stay as zeroed at creation
+                  MODE == M_ROLLOUT || MODE == M_INIT || MODE == M_SPLIT_INIT, MEM, !a.idx);   // 1-player: FIFO words stay as zeroed at creation
     report_status(a, g.status);
 }
 
@@ -265,8 +267,8 @@ template <int STAGE, bool TINT = false>
 TE_HD void split_body(const KArgs& a, int i, const uint32_t* shapes) {
     Ctx cx = make_ctx(a, shapes, TINT);
     Game<1> g;
-    const uint32_t my_a = STAGE > 0 ? a.xw[i] : 0u;
-    const uint32_t opp_a = STAGE > 0 ? a.xw[(size_t)a.n + i] : 0u;
+    const uint32_t my_a = STAGE > 0 ? a.xw[0][i] : 0u;
+    const uint32_t opp_a = STAGE > 0 ? a.xw[1][i] : 0u;
     // side 1 continues from its speculative post-settle state unless player 0 died in loop 1
     const uint32_t meta = word_at(game_ref(geo_of(a), (size_t)i), G_META);
     const int side = (int)((meta >> 21) & 1u);
@@ -298,7 +300,7 @@ TE_HD void split_body(const KArgs& a, int i, const uint32_t* shapes) {
             const int in = (!i_died && (opp_a & XW_RAN) && !(opp_a & XW_DIED)) ? xw_sent(opp_a) : 0;
             w = split_tick(cx, g, a.ms, in);
         } else {
-            const uint32_t opp_b = a.xw[(size_t)2 * a.n + i];
+            const uint32_t opp_b = a.xw[2][i];
             const int in1 = ((opp_a & XW_RAN) && !(opp_a & XW_DIED)) ? xw_sent(opp_a) : 0;
             if (!g.round_over && in1 > 0) q.incoming = q.incoming + (float)in1 / 1.0f;   // loop 1, PythonHandle.cpp:121
             const int in2 = (opp_b & XW_DIED) ? 0 : xw_sent(opp_b);                      // loop 2, :175
@@ -309,7 +311,7 @@ TE_HD void split_body(const KArgs& a, int i, const uint32_t* shapes) {
         g.add_sent += (q.lines_sent - sent_before) & 0xFFFFu;
         store_game<1>(geo_of(a), (size_t)i, g, TINT);
     } else {
-        const uint32_t opp_b = a.xw[(size_t)(side == 0 ? 3 : 2) * a.n + i];
+        const uint32_t opp_b = a.xw[side == 0 ? 3 : 2][i];
         const int in = (side == 0 && !(opp_b & XW_DIED)) ? xw_sent(opp_b) : 0;
         const int done = split_finish(g, in, (opp_b & XW_DEAD_NOW) != 0, (opp_b & XW_ERR) != 0);
         if (a.done) a.done[i] = (uint8_t)done;
@@ -418,7 +420,10 @@ TE_HD int observe_board(const Geo& geo, size_t slot, int p, int H, uint8_t* cell
 //             pre[x] & suf[x + 4] & (the four columns under the piece | its cells) — no pass over all ten columns
 // A placement lane then needs ~10 LDS reads and no loop over the board.
 constexpr int PRE_COL = 0, PRE_PIECE = 10, PRE_BAND = 11, PRE_STRIP = 13, PRE_PRE = 17, PRE_SUF = 28, PRE_WORDS = 40;
-constexpr int ENUM_BOARDS = 32, ENUM_BLOCK = ENUM_BOARDS * 10;     // boards / threads per workgroup of k_enumerate (10 lanes per board)
+#ifndef TE_ENUM_BOARDS
+#define TE_ENUM_BOARDS 32
+#endif
+constexpr int ENUM_BOARDS = TE_ENUM_BOARDS, ENUM_BLOCK = ENUM_BOARDS * 10;     // boards / threads per workgroup of k_enumerate (10 lanes per board)
 
 // element functions of the per-board precompute (lane j of a board calls the ones its index selects)
 TE_HD uint32_t pre_band_bits(uint32_t col, uint32_t floor_bits, int c, int& word) {      // nibble c+2 of the 64-bit band

@@ -88,7 +88,7 @@ enum Flag : int {
 struct Ref { uint32_t* s; uint32_t o; size_t ws; };
 
 // Geometry of one batch: N games, P players, nw words per player-board; `state` and `gstate` are its allocations.
-struct Geo { uint32_t* state; uint32_t* gstate; size_t n_games; int P; int nw; };
+struct Geo { uint32_t* state; uint32_t* gstate; size_t n_games; int P; int nw; size_t stride; };     // stride: games per row (>= n_games)
 
 #if defined(__HIPCC__)
 #define TE_LAYOUT_HD __host__ __device__ __forceinline__
@@ -96,19 +96,55 @@ struct Geo { uint32_t* state; uint32_t* gstate; size_t n_games; int P; int nw; }
 #define TE_LAYOUT_HD static inline
 #endif
 
-// layout "rows": state[(w * P + p) * N + slot], gstate[gw * N + slot]
-TE_LAYOUT_HD Ref board_ref(const Geo& g, int p, size_t slot) {
-    Ref r = {g.state + (size_t)p * g.n_games, (uint32_t)slot * 4u, (size_t)g.P * g.n_games};
+// Layout "rows" (default): state[(w * P + p) * N + slot], gstate[gw * N + slot] — word w of all games is one contiguous row.
+// Layout "tiles" (-DTE_TILED=1, kept for same-box A/B): the batch is cut into tiles of 64 consecutive games — the games of one
+// wavefront — and a tile is contiguous: [NGWORDS game words][nw words x P players], 64 lanes each, i.e. word w of player p of
+// game g lives at state[(g / 64) * tile_words + (NGWORDS + w * P + p) * 64 + g % 64].  Every access of a wave is one coalesced
+// 256-byte row in both layouts; with tiles all rows of a wave sit at COMPILE-TIME offsets from one base (immediate offsets: no
+// address arithmetic, -74 scalar instructions per step) and the ~8 KB a wave touches are one contiguous block.  MEASURED
+// (profiles/r02/layout_chain_ab.txt, same box, 64k single-player boards, one step per launch): tiles 6.24 us per launch, rows
+// 5.79 us (chained launches: 5.25 vs 5.00 us).  The step is bound by the latency of its ~30 loads, not by instruction count:
+// thirty rows that lie N * 4 bytes apart are thirty requests to different memory channels, while one contiguous 8 KB block
+// queues on a few.  With tiles `gstate` is the batch's main state allocation (`state` may point at a second allocation of the
+// same shape — the shadow copy of split batches — whose game words are not used).
+#ifndef TE_TILED
+#define TE_TILED 0
+#endif
+constexpr int TILE = 64;
+#if defined(__HIP_DEVICE_COMPILE__)
+TE_LAYOUT_HD size_t wave_uniform(size_t v) { return (size_t)__builtin_amdgcn_readfirstlane((uint32_t)v); }   // same value in all lanes, told to the compiler
+#else
+TE_LAYOUT_HD size_t wave_uniform(size_t v) { return v; }
+#endif
+#if TE_TILED
+TE_LAYOUT_HD size_t tile_words(const Geo& g) { return (size_t)(NGWORDS + g.nw * g.P) * TILE; }
+// `uniform`: the lanes of the calling wave hold the 64 games of ONE tile (slot = 64 * wave + lane): the base is then a scalar
+TE_LAYOUT_HD Ref board_ref(const Geo& g, int p, size_t slot, bool uniform = false) {
+    const size_t tile = uniform ? wave_uniform(slot / TILE) : slot / TILE;
+    Ref r = {g.state + tile * tile_words(g) + (size_t)(NGWORDS + p) * TILE, (uint32_t)(slot % TILE) * 4u, (size_t)g.P * TILE};
     return r;
 }
-TE_LAYOUT_HD Ref game_ref(const Geo& g, size_t slot) {
-    Ref r = {g.gstate, (uint32_t)slot * 4u, g.n_games};
+TE_LAYOUT_HD Ref game_ref(const Geo& g, size_t slot, bool uniform = false) {
+    const size_t tile = uniform ? wave_uniform(slot / TILE) : slot / TILE;
+    Ref r = {g.gstate + tile * tile_words(g), (uint32_t)(slot % TILE) * 4u, (size_t)TILE};      // (gstate: the batch's main allocation)
     return r;
 }
-// plain (cached) access to one word, for the kernels that touch a few words of many games
-TE_LAYOUT_HD uint32_t& word_at(const Ref& r, int w) { return *(uint32_t*)((char*)(r.s + (size_t)w * r.ws) + r.o); }
-// allocation sizes in words
+// player words follow the game words: word w of a board_ref = row NGWORDS + w * P + p of the tile
+TE_LAYOUT_HD size_t state_words(size_t n_games, int P, int nw) { return ((n_games + TILE - 1) / TILE) * (size_t)(NGWORDS + nw * P) * TILE; }
+TE_LAYOUT_HD size_t gstate_words(size_t) { return 0; }
+#else
+TE_LAYOUT_HD Ref board_ref(const Geo& g, int p, size_t slot, bool = false) {
+    Ref r = {g.state + (size_t)p * g.stride, (uint32_t)slot * 4u, (size_t)g.P * g.stride};
+    return r;
+}
+TE_LAYOUT_HD Ref game_ref(const Geo& g, size_t slot, bool = false) {
+    Ref r = {g.gstate, (uint32_t)slot * 4u, g.stride};
+    return r;
+}
 TE_LAYOUT_HD size_t state_words(size_t n_games, int P, int nw) { return (size_t)nw * P * n_games; }
 TE_LAYOUT_HD size_t gstate_words(size_t n_games) { return (size_t)NGWORDS * n_games; }
+#endif
+// plain (cached) access to one word, for the kernels that touch a few words of many games
+TE_LAYOUT_HD uint32_t& word_at(const Ref& r, int w) { return *(uint32_t*)((char*)(r.s + (size_t)w * r.ws) + r.o); }
 
 }  // namespace te

@@ -99,13 +99,32 @@ class SplitOpponents:
         z = lambda *shape, dt=torch.uint8: torch.zeros(*shape, dtype=dt, device=self.dev)
         self.rot, self.trans, self.acting = z(self.n), z(self.n), z(self.n)
         self.done, self.lines, self.dead = z(self.n), z(self.n), z(self.n)
-        self.words = z(4, self.n, dt=torch.int32)          # my A, opponent's A, player 0's B, player 1's B
-        self.out = z(self.n, dt=torch.int32)
-        self.gathered = z(self.world, self.n, dt=torch.int32)
+        # Exchange words: what my kernels write (A, B) and one gather buffer per exchange.  Every stage reads the words where
+        # they lie — its own output or the peer's row of a gather buffer — so a step is 3 kernels + 3 all-gathers and nothing
+        # else: no copies, no allocation (`zero` is what the side that has nothing to say in an exchange contributes).
+        self.a_mine, self.b_mine, self.zero = z(self.n, dt=torch.int32), z(self.n, dt=torch.int32), z(self.n, dt=torch.int32)
+        self.g1, self.g2, self.g3 = (z(self.world, self.n, dt=torch.int32) for _ in range(3))
+        B = self.batch
+        opp_a = self.g1[self.peer].data_ptr()
+        b0 = self.b_mine.data_ptr() if self.side == 0 else self.g2[self.peer].data_ptr()
+        b1 = self.g3[self.peer].data_ptr() if self.side == 0 else self.b_mine.data_ptr()
+        self.words = B.split_words(self.a_mine.data_ptr(), opp_a, b0, b1)
 
-    def _exchange(self, mine):
-        self.dist.all_gather_into_tensor(self.gathered.view(-1), mine)
-        return self.gathered[self.peer]
+    def _step(self, stage0, stage1, stage2):
+        """The stage protocol of one step (csrc/tetris_engine.h "split mode"): exchange 1 = loop-1 words both ways,
+        exchange 2 = player 0's tick words, exchange 3 = player 1's tick words."""
+        gather = self.dist.all_gather_into_tensor
+        stage0(self.a_mine.data_ptr())
+        gather(self.g1.view(-1), self.a_mine)
+        if self.side == 0:
+            stage1(self.b_mine.data_ptr())
+            gather(self.g2.view(-1), self.b_mine)
+            gather(self.g3.view(-1), self.zero)
+        else:
+            gather(self.g2.view(-1), self.zero)
+            stage1(self.b_mine.data_ptr())
+            gather(self.g3.view(-1), self.b_mine)
+        stage2()
 
     def step_rt(self, rot, trans, acting, ms=400):
         """One env-step of all games: player acting[g] of game g plays (rot[g], trans[g]).  -> done, lines, dead (numpy, my side)."""
@@ -113,49 +132,25 @@ class SplitOpponents:
         for dst, src in ((self.rot, rot), (self.trans, trans), (self.acting, acting)):
             dst.copy_(t.as_tensor(np.ascontiguousarray(src, dtype=np.uint8)), non_blocking=True)
         B, w = self.batch, self.words
-        B.split_stage(0, rot=self.rot.data_ptr(), trans=self.trans.data_ptr(), acting=self.acting.data_ptr(), out=self.out.data_ptr(), ms=ms)
-        w[0].copy_(self.out)
-        w[1].copy_(self._exchange(self.out))                                   # exchange 1: loop-1 results
-        zero = t.zeros_like(self.out)
-        if self.side == 0:
-            B.split_stage(1, words=w.data_ptr(), out=self.out.data_ptr(), ms=ms)
-            w[2].copy_(self.out)
-            self._exchange(self.out)                                           # exchange 2: player 0's tick
-            w[3].copy_(self._exchange(zero))                                   # exchange 3: player 1's tick
-        else:
-            w[2].copy_(self._exchange(zero))
-            B.split_stage(1, words=w.data_ptr(), out=self.out.data_ptr(), ms=ms)
-            w[3].copy_(self.out)
-            self._exchange(self.out)
-        B.split_stage(2, words=w.data_ptr(), done=self.done.data_ptr(), lines=self.lines.data_ptr(), dead=self.dead.data_ptr(), ms=ms)
+        self._step(lambda out: B.split_stage(0, rot=self.rot.data_ptr(), trans=self.trans.data_ptr(), acting=self.acting.data_ptr(), out=out, ms=ms),
+                   lambda out: B.split_stage(1, words=w, out=out, ms=ms),
+                   lambda: B.split_stage(2, words=w, done=self.done.data_ptr(), lines=self.lines.data_ptr(), dead=self.dead.data_ptr(), ms=ms))
         if self.on_gpu:
             t.cuda.current_stream(self.dev).synchronize()
         return self.done.cpu().numpy().copy(), self.lines.cpu().numpy().copy(), self.dead.cpu().numpy().copy()
 
     def rollout(self, steps, first_step=0, policy_seed=0xD71, ms=400):
         """`steps` env-steps of the built-in synthetic rollout on every game (policy, acting player and auto-reset are
-        computed on the device, identically on both sides): per step three kernels and three all-gathers, no host
+        computed on the device, identically on both sides): per step three kernels and three all-gathers, no copies and no host
         synchronisation in between.  -> seconds (wall, after a final stream sync)."""
         t, B, w = self.torch, self.batch, self.words
-        zero = t.zeros_like(self.out)
         if self.on_gpu:
             t.cuda.current_stream(self.dev).synchronize()
         t0 = time.perf_counter()
         for s in range(first_step, first_step + steps):
-            B.split_rollout_stage(0, s, out=self.out.data_ptr(), policy_seed=policy_seed, ms=ms)
-            w[0].copy_(self.out)
-            w[1].copy_(self._exchange(self.out))
-            if self.side == 0:
-                B.split_rollout_stage(1, s, words=w.data_ptr(), out=self.out.data_ptr(), policy_seed=policy_seed, ms=ms)
-                w[2].copy_(self.out)
-                self._exchange(self.out)
-                w[3].copy_(self._exchange(zero))
-            else:
-                w[2].copy_(self._exchange(zero))
-                B.split_rollout_stage(1, s, words=w.data_ptr(), out=self.out.data_ptr(), policy_seed=policy_seed, ms=ms)
-                w[3].copy_(self.out)
-                self._exchange(self.out)
-            B.split_rollout_stage(2, s, words=w.data_ptr(), policy_seed=policy_seed, ms=ms)
+            self._step(lambda out: B.split_rollout_stage(0, s, out=out, policy_seed=policy_seed, ms=ms),
+                       lambda out: B.split_rollout_stage(1, s, words=w, out=out, policy_seed=policy_seed, ms=ms),
+                       lambda: B.split_rollout_stage(2, s, words=w, policy_seed=policy_seed, ms=ms))
         if self.on_gpu:
             t.cuda.current_stream(self.dev).synchronize()
         return time.perf_counter() - t0

@@ -207,6 +207,14 @@ int tetris_rollout_random(tetris_batch *b, int launches, int steps_per_launch, u
 int tetris_rollout_launch(tetris_batch *b, int launches, int steps_per_launch, uint32_t policy_seed,
                           uint64_t first_step, int ms, float *elapsed_ms);
 
+/* Chained launches of the built-in rollout (default on; single-player batches on their own stream, one or more steps per
+ * launch): a game's step E depends only on the same game's step E - 1, so consecutive launches are put on two streams
+ * alternately and ordered per WAVE — the 64 games of a wave wait, inside the kernel, for an epoch word that the same wave
+ * of the previous launch publishes after its state stores have drained — instead of per launch by the stream (where every
+ * launch waits for the slowest wave of the whole previous launch plus the kernel boundary).  Results are bit-identical.
+ * on = 0: every launch on the batch's one stream.  (Environment: TETRIS_NO_CHAIN=1 sets the default to off.)           */
+int tetris_set_chained(tetris_batch *b, int on);
+
 /* Global id of this batch's game 0 (default 0): the built-in rollout keys its policy and its
  * reset-seed schedule by global game id, so that N batches on N GPUs simulate N*n_games distinct
  * games (the reference's equivalent: N worker containers, docker-compose.yaml:27).               */
@@ -220,21 +228,26 @@ int tetris_set_game_offset(tetris_batch *b, uint64_t first_game_id);
  *   stage 0: key interpreter for the acting side ([8]*r+[2]+[3]*t+[7]) + loop 1 (side 1 speculatively) -> words A
  *   stage 1: delayCheck of my player.  Side 0 runs it after the A exchange, side 1 after player 0's B words arrived
  *   stage 2: lines arriving after my tick, winner / round_over -> done[n], lines[n], dead[n] (any may be NULL)
- * d_words [4][n] uint32 (device): row 0 my A words, row 1 the opponent's A words, row 2 player 0's B words, row 3
- * player 1's B words (rows not yet exchanged are not read).  d_out [n]: this stage's words (stages 0, 1).
- * All pointers are device pointers; everything is enqueued on the batch's stream.  tetris_reset() on a split batch
- * applies the two-player winner rule.                                                                            */
+ * d_words: HOST array of four device pointers to uint32 [n] — my A words, the opponent's A words, player 0's B words,
+ * player 1's B words (entries a stage does not read may be NULL): the words a stage wrote (d_out) and the rows an
+ * all-gather delivered are read where they lie, nothing is copied in between.  d_out [n]: this stage's words (stages 0, 1).
+ * All data pointers are device pointers; everything is enqueued on the batch's stream.  tetris_reset() on a split
+ * batch applies the two-player winner rule.
+ * Why three exchanges and not two: within one step the reference's order makes player 0's tick depend on player 1's loop-1
+ * words (A), player 1's tick on player 0's tick words (B0), and `done` on player 1's tick words (B1) — three messages that
+ * depend on each other.  Folding B1 into the next step's A exchange would need a second speculative shadow state on side 0
+ * (it would play the next key list before knowing whether the round had ended) and deliver `done` one step late.      */
 int tetris_create_split(tetris_batch **out, int n_games, int side, int height, int width,
                         const uint8_t piece_map[7], int device, const int16_t *seeds);
 int tetris_split_stage_dev(tetris_batch *b, int stage, const uint8_t *d_rot, const uint8_t *d_trans,
-                           const uint8_t *d_acting, int ms, const uint32_t *d_words, uint32_t *d_out,
+                           const uint8_t *d_acting, int ms, const uint32_t *const d_words[4], uint32_t *d_out,
                            uint8_t *d_done, uint8_t *d_lines, uint8_t *d_dead);
 /* One stage of a split-mode step of the built-in synthetic rollout (same policy and reset-seed schedule as
  * tetris_rollout_random, keyed by global game id and `step`; acting player = step mod 2): stage 0 draws the action on
  * the device, stage 2 counts and auto-resets finished games — identically on both sides, so no host round trip is
  * needed inside a rollout.  d_words / d_out as for tetris_split_stage_dev.                                          */
 int tetris_split_rollout_stage_dev(tetris_batch *b, int stage, uint32_t policy_seed, uint64_t step, int ms,
-                                   const uint32_t *d_words, uint32_t *d_out);
+                                   const uint32_t *const d_words[4], uint32_t *d_out);
 /* cumulative counters of the built-in rollouts of this batch: totals[4] = {env_steps, episodes, lines_cleared,
  * garbage_sent}, each the sum over the games of a per-game word the step kernels keep (env_steps is COUNTED on the
  * device, one increment per game and step, not computed from the launch arguments); synchronous.                  */

@@ -84,14 +84,14 @@ struct tetris_batch {
 static KArgs base_args(tetris_batch* b, int n, const int32_t* idx) {
     KArgs a;
     memset(&a, 0, sizeof a);
-    a.state = b->state.data(); a.gstate = b->gstate.data(); a.status = b->flags;
+    a.state = b->state.data(); a.gstate = b->gstate.empty() ? b->state.data() : b->gstate.data(); a.status = b->flags;
     a.table = b->tab->table.data(); a.start = b->tab->start.data(); a.combo_pow = b->tab->powtab;
     a.n_draws = (uint32_t)b->tab->n_chunks * CHUNK; a.margin = b->margin;
-    a.H = b->H; a.n_games = b->N; a.n_players = b->P; a.nw = b->nw; a.n = n; a.idx = idx; a.game_offset = b->game_offset;
+    a.H = b->H; a.n_games = b->N; a.n_stride = b->N; a.n_players = b->P; a.nw = b->nw; a.n = n; a.idx = idx; a.game_offset = b->game_offset;
     return a;
 }
 static Geo geo_of_batch(tetris_batch* b) {
-    Geo g = {b->state.data(), b->gstate.data(), (size_t)b->N, b->P, b->nw};
+    Geo g = {b->state.data(), b->gstate.empty() ? b->state.data() : b->gstate.data(), (size_t)b->N, b->P, b->nw, (size_t)b->N};
     return g;
 }
 
@@ -202,13 +202,11 @@ int tetris_create_split(tetris_batch** out, int n_games, int side, int height, i
     return create_impl(out, n_games, 1, height, width, piece_map, seeds, 1, side);
 }
 int tetris_set_stream(tetris_batch*, void*, int) { return TETRIS_OK; }
-int tetris_split_stage_dev(tetris_batch* b, int stage, const uint8_t* rot, const uint8_t* trans, const uint8_t* acting, int ms,
-                           const uint32_t* words, uint32_t* outw, uint8_t* done, uint8_t* lines, uint8_t* dead) {
+static int split_stage_run(tetris_batch* b, int stage, KArgs& a, const uint32_t* const words[4], uint32_t* outw) {
     if (!b->split) return fail(TETRIS_E_ARG, "not a split batch");
     if (stage < 0 || stage > 2) return fail(TETRIS_E_ARG, "stage");
-    KArgs a = base_args(b, b->N, nullptr);
-    a.rot = rot; a.trans = trans; a.player = acting; a.ms = ms;
-    a.shadow = b->shadow.data(); a.xw = words; a.xout = outw; a.done = done; a.lines = lines; a.dead = dead;
+    for (int k = 0; k < 4; k++) a.xw[k] = words ? words[k] : nullptr;
+    a.shadow = b->shadow.data(); a.xout = outw;
     for (int i = 0; i < b->N; i++) {
         if (stage == 0) split_body<0>(a, i, SHAPES.s);
         else if (stage == 1) split_body<1>(a, i, SHAPES.s);
@@ -216,19 +214,17 @@ int tetris_split_stage_dev(tetris_batch* b, int stage, const uint8_t* rot, const
     }
     return TETRIS_OK;
 }
-int tetris_split_rollout_stage_dev(tetris_batch* b, int stage, uint32_t policy_seed, uint64_t step, int ms, const uint32_t* words,
+int tetris_split_stage_dev(tetris_batch* b, int stage, const uint8_t* rot, const uint8_t* trans, const uint8_t* acting, int ms,
+                           const uint32_t* const words[4], uint32_t* outw, uint8_t* done, uint8_t* lines, uint8_t* dead) {
+    KArgs a = base_args(b, b->N, nullptr);
+    a.rot = rot; a.trans = trans; a.player = acting; a.ms = ms; a.done = done; a.lines = lines; a.dead = dead;
+    return split_stage_run(b, stage, a, words, outw);
+}
+int tetris_split_rollout_stage_dev(tetris_batch* b, int stage, uint32_t policy_seed, uint64_t step, int ms, const uint32_t* const words[4],
                                    uint32_t* outw) {
-    if (!b->split) return fail(TETRIS_E_ARG, "not a split batch");
-    if (stage < 0 || stage > 2) return fail(TETRIS_E_ARG, "stage");
     KArgs a = base_args(b, b->N, nullptr);
     a.ms = ms; a.policy_seed = policy_seed; a.first_step = step; a.steps = 1;
-    a.shadow = b->shadow.data(); a.xw = words; a.xout = outw;
-    for (int i = 0; i < b->N; i++) {
-        if (stage == 0) split_body<0>(a, i, SHAPES.s);
-        else if (stage == 1) split_body<1>(a, i, SHAPES.s);
-        else split_body<2>(a, i, SHAPES.s);
-    }
-    return TETRIS_OK;
+    return split_stage_run(b, stage, a, words, outw);
 }
 int tetris_rollout_totals(tetris_batch* b, uint64_t totals[4]) {
     totals[0] = totals[1] = totals[2] = totals[3] = 0;
@@ -247,6 +243,7 @@ int tetris_take_errors(tetris_batch* b, uint32_t* bits) {
     b->flags[F_FIFO] = 0; b->flags[F_EXHAUSTED] = 0;
     return TETRIS_OK;
 }
+int tetris_set_chained(tetris_batch*, int) { return TETRIS_OK; }
 int tetris_set_game_offset(tetris_batch* b, uint64_t first) { b->game_offset = (uint32_t)first; return TETRIS_OK; }
 
 static int check_idx(tetris_batch* b, const int32_t* idx, int n) {
