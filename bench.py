@@ -189,7 +189,7 @@ def main():
     res = shard.run(args.steps, S)                    # exactly K timed launches
     counters, wall, ev_ms = res["counters"], res["wall_s"], res["event_ms"]
     batch = shard
-    chained = P == 1 and os.environ.get("TETRIS_NO_CHAIN") != "1"
+    chained = (P == 1 or (P == 2 and S == 1 and os.environ.get("TETRIS_NO_DUO") != "1")) and os.environ.get("TETRIS_NO_CHAIN") != "1"
     unchained = None
     if chained and S == 1:
         # reference point, NOT the headline: the same K launches on ONE stream, where every launch waits for the whole previous
@@ -198,7 +198,7 @@ def main():
         shard.run(min(args.warmup, 8), S)
         r2 = shard.run(args.steps, S)
         shard.batch.set_chained(True)
-        unchained = {"kernel": "k_game<1, M_ROLLOUT>", "launch_us": r2["wall_s"] * 1e6 / args.steps,
+        unchained = {"kernel": "k_game<1, M_ROLLOUT>" if P == 1 else "k_duo<M_ROLLOUT>", "launch_us": r2["wall_s"] * 1e6 / args.steps,
                      "launch_us_events": r2["event_ms"] * 1e3 / args.steps if r2["event_ms"] > 0 else None}
 
     if rank == 0:
@@ -213,7 +213,7 @@ def main():
         launch_us_events = ev_ms * 1e3 / args.steps if ev_ms > 0 else None     # (the CPU rehearsal library has no events)
         lib_path = os.path.abspath(os.environ.get("BENCH_LIB_PATH") or ge.LIB)
         roofline = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "kernel": "k_chain<1> (chained launches: two streams, each wave waits for its own predecessor's epoch word)" if chained
+                    "kernel": ("k_chain<1>" if P == 1 else "k_duo<M_ROLLOUT, chained>") + " (chained launches: two streams, each wave waits for its own predecessor's epoch word)" if chained
                               else ("k_duo<M_ROLLOUT>" if (P == 2 and S == 1) else f"k_game<{P}, M_ROLLOUT>"),
                     "launch_us": launch_us, "launch_us_events": launch_us_events, "clock": "wall (same clock as `value`)"}
         if chained:

@@ -111,7 +111,9 @@ __global__ __launch_bounds__(256) void k_totals(Geo geo, unsigned long long* out
 // the first's.  The in-step order dependence between the players is the split-mode stage protocol (tetris_engine.h) with
 // the exchange words moved by __shfl_xor(.., 32): A = key interpreter + loop 1 (player 1 speculatively, with a register
 // backup for the rollback when player 0 died), B0 / B1 = delayCheck of player 0, then player 1, C = winner logic.
-template <int MODE>
+// CHAIN (rollout only, 64-thread workgroups): chained launches as in k_chain — a wave's 32 games wait for the epoch word the same
+// wave of the previous launch published, and all state traffic is agent-scope.
+template <int MODE, bool CHAIN = false>
 __global__ __launch_bounds__(256) void k_duo(KArgs a) {
     __shared__ __attribute__((aligned(16))) uint32_t s_shapes_all[4][SHAPE_WORDS];      // per-wave copy, no block barrier (see k_game)
     uint32_t* s_shapes = s_shapes_all[threadIdx.x >> 6];
@@ -121,15 +123,25 @@ __global__ __launch_bounds__(256) void k_duo(KArgs a) {
     const int gi = wave * 32 + (lane & 31);
     const bool active = gi < a.n;
     constexpr bool ROLL = MODE == M_ROLLOUT, AUTO = MODE == M_STEP_RT_AUTO;
+    constexpr int MEM = CHAIN ? MEM_AGENT : MEM_STREAM;
     Geo geo = geo_of(a);
     geo.P = 2;                           // compile-time stride factor for the hot loads
     const Ref gr = game_ref(geo, (size_t)gi, true), br = board_ref(geo, side, (size_t)gi);     // the wave's 32 games lie in one tile
     Game<1> g;
     Player& q = g.pl[0];
+    uint32_t pd0 = 0, pd1 = 0;
+    if (CHAIN) {
+        if (active) policy_draw(a, (uint32_t)gi, a.first_step, pd0, pd1);        // while the wave waits for its predecessor
+        if (!chain_wait(a, (uint32_t)wave)) {
+            if (lane == 0) { ((volatile uint32_t*)a.status)[F_CHAIN] = 1u; st_agent(a.chain + wave, CHAIN_POISON); }
+            return;
+        }
+    }
     if (active) {
-        load_game_words<1>(gr, g, ROLL);
-        load_player(br.s, br.o, br.ws, q, false);
-        if (ROLL) policy_draw(a, (uint32_t)gi, a.first_step, g.draw0, g.draw1);   // under the loads (see game_load)
+        load_game_words<1>(gr, g, ROLL, MEM);
+        load_player(br.s, br.o, br.ws, q, false, true, MEM);
+        if (CHAIN) { g.draw0 = pd0; g.draw1 = pd1; }
+        else if (ROLL) policy_draw(a, (uint32_t)gi, a.first_step, g.draw0, g.draw1);   // under the loads (see game_load)
         else { g.draw0 = a.rot[gi]; g.draw1 = (uint32_t)a.trans[gi] | ((a.player ? (uint32_t)a.player[gi] : 0u) << 8); }
     }
     s_shapes[lane] = shape_word;
@@ -196,7 +208,7 @@ __global__ __launch_bounds__(256) void k_duo(KArgs a) {
     }
     const uint32_t opp_lines = __shfl_xor(my_lines, 32), opp_sent = __shfl_xor(my_sent, 32);
     if (active) {
-        store_player(br.s, br.o, br.ws, q, false);
+        store_player(br.s, br.o, br.ws, q, false, true, MEM);
         if (!ROLL) {
             if (a.lines) a.lines[(size_t)side * a.n + gi] = (uint8_t)out_reward;
             if (a.dead) a.dead[(size_t)side * a.n + gi] = (uint8_t)out_dead;
@@ -207,9 +219,13 @@ __global__ __launch_bounds__(256) void k_duo(KArgs a) {
             g.flags = 0;
             g.add_lines = my_lines + opp_lines;
             g.add_sent = my_sent + opp_sent;
-            store_game_words<1>(gr, g, ROLL);
+            store_game_words<1>(gr, g, ROLL, MEM);
             report_status(a, st);
         }
+    }
+    if (CHAIN) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every store (and counter atomic) of this wave has been acknowledged
+        if (lane == 0) st_agent(a.chain + wave, a.epoch);
     }
 }
 
@@ -835,7 +851,7 @@ static int create_impl(tetris_batch** out, int n_games, int n_players, int heigh
     for (int k = 0; k < 2; k++) CREATE_TRY(hipStreamCreateWithFlags(&b->chain_stream[k], hipStreamNonBlocking));
     for (int k = 0; k < 3; k++) CREATE_TRY(hipEventCreateWithFlags(&b->chain_ev[k], hipEventDisableTiming));
     {
-        const size_t chain_bytes = (((size_t)n_games + CHAIN_LANES - 1) / CHAIN_LANES) * sizeof(uint32_t);
+        const size_t chain_bytes = (((size_t)n_games + 15) / 16) * sizeof(uint32_t);       // (one word per wave; at least 16 games per wave)
         CREATE_TRY(hipMalloc((void**)&b->d_chain, chain_bytes));
         CREATE_TRY(hipMemsetAsync(b->d_chain, 0, chain_bytes, b->stream));
     }
@@ -1451,7 +1467,8 @@ int tetris_rollout_launch(tetris_batch* b, int launches, int steps_per_launch, u
     if (b->margin < need) b->margin = need;
     // single-player batches on their own stream: chained launches (k_chain) — consecutive launches alternate between two
     // streams and each wave waits for its own predecessor only, not for the slowest wave of the whole previous launch
-    const bool chained = b->use_chain && b->P == 1 && !b->tint && !b->split && b->stream == b->own_stream && steps_per_launch >= 1;
+    const bool chained = b->use_chain && !b->tint && !b->split && b->stream == b->own_stream &&
+                         ((b->P == 1 && steps_per_launch >= 1) || (b->P == 2 && steps_per_launch == 1 && b->use_duo));
     hipStream_t const home = b->stream;
     if (chained && b->home_async) {
         // both chain streams start behind the asynchronous work the batch's stream still holds (after a synchronous call it
@@ -1472,7 +1489,8 @@ int tetris_rollout_launch(tetris_batch* b, int launches, int steps_per_launch, u
         a.first_step = first_step + (uint64_t)l * (uint64_t)steps_per_launch;
         if (chained) {
             a.chain = b->d_chain; a.epoch = ++b->chain_epoch;
-            hipLaunchKernelGGL((k_chain<1>), dim3((unsigned)((b->N + CHAIN_LANES - 1) / CHAIN_LANES)), dim3(64), 0, b->stream, a);
+            if (b->P == 1) hipLaunchKernelGGL((k_chain<1>), dim3((unsigned)((b->N + CHAIN_LANES - 1) / CHAIN_LANES)), dim3(64), 0, b->stream, a);
+            else hipLaunchKernelGGL((k_duo<M_ROLLOUT, true>), dim3((unsigned)((b->N + 31) / 32)), dim3(64), 0, b->stream, a);
             HIP_TRY(hipGetLastError());
         } else if ((rc = launch_game<M_ROLLOUT>(b, a)))
             return rc;
