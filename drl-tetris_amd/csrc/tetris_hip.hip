@@ -1468,7 +1468,7 @@ int tetris_rollout_launch(tetris_batch* b, int launches, int steps_per_launch, u
     // single-player batches on their own stream: chained launches (k_chain) — consecutive launches alternate between two
     // streams and each wave waits for its own predecessor only, not for the slowest wave of the whole previous launch
     const bool chained = b->use_chain && !b->tint && !b->split && b->stream == b->own_stream &&
-                         ((b->P == 1 && steps_per_launch >= 1) || (b->P == 2 && steps_per_launch == 1 && b->use_duo));
+                         (b->P == 1 || (b->P == 2 && steps_per_launch == 1 && b->use_duo));
     hipStream_t const home = b->stream;
     if (chained && b->home_async) {
         // both chain streams start behind the asynchronous work the batch's stream still holds (after a synchronous call it

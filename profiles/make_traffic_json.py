@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""profiles/pmc_p{P}_s{S}.json (read by bench.py for roofline.traffic) from a pmc_passes.sh summary.
+"""profiles/<round>/pmc_p{P}_s{S}.json (read by bench.py for roofline.traffic) from a pmc_passes.sh summary.
+usage: make_traffic_json.py <summary.json> <P> <S> <out.json> [kernel-name substring]
 HBM-side bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) KiB: WRITE_SIZE is exact and FETCH_SIZE reads 1/2 on
 gfx950 for this kernel's access pattern — calibrated with profiles/calib.py (zero-step launches moving exactly
 29 words x 4 B x 65536 games = 7424 KiB written, 28 read: WRITE_SIZE 7424 KiB exact, FETCH_SIZE 3610 KiB = 1/2 of the 7168 KiB + kernel arguments), as
@@ -8,9 +9,11 @@ one-byte RNG-table reads it is an upper bound.  Infinity-Cache hits are included
 import json, sys
 summary, P, S, out = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
 d = json.load(open(summary))
-k = [v for name, v in d.items() if f"k_game<{P}, 6" in name or (P == 2 and "k_duo<6>" in name)][0]
+want = sys.argv[5] if len(sys.argv) > 5 else None
+names = [name for name in d if (want in name if want else (f"k_game<{P}, 6" in name or "k_chain" in name or "k_duo<6" in name))]
+k = d[names[0]]
 res = {
-    "kernel": "k_duo<M_ROLLOUT>" if any("k_duo<6>" in n for n in d) and P == 2 else f"k_game<{P}, M_ROLLOUT>", "steps_per_launch": S, "games": 65536,
+    "kernel": names[0], "steps_per_launch": S, "games": 65536,
     "FETCH_SIZE_KiB_raw": k["FETCH_SIZE"], "WRITE_SIZE_KiB": k["WRITE_SIZE"],
     "fetch_correction": 2.0,
     "hbm_bytes_per_launch": int((2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024),

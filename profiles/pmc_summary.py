@@ -23,7 +23,7 @@ for k, cs in acc.items():
     out[k]["_dispatches"] = max(v[1] for v in cs.values())
 json.dump(out, open(os.path.join(d, "summary.json"), "w"), indent=1)
 for k, cs in out.items():
-    if "k_game" in k:
+    if "k_game" in k or "k_chain" in k or "k_duo" in k:
         print(k)
         for c, v in sorted(cs.items()):
             print(f"   {c:28s} {v:16.1f}")

@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Per-stage device times of split mode (BASELINE config 5) at its per-GPU size: 65 536 two-player games, side 0 and side 1
+as two batches on THE ONE GPU of the test box, on one stream, each stage reading the other side's exchange words where that
+side's kernel wrote them (what an all-gather would deliver).  Steady-state built-in rollout (policy and auto-reset on the
+device).  Prints HIP-event time per step; run under `rocprofv3 --kernel-trace --stats` for the per-kernel rows
+(k_split<0> = key interpreter + loop 1, k_split<1> = delayCheck, k_split<2> = winner logic / reset)."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import json
+
+import numpy as np
+import torch
+
+import __graft_entry__ as ge
+from oracle import oracle as orc  # (seed schedule helper only)
+
+pkg = ge.package()
+n, steps = 65536, int(sys.argv[1]) if len(sys.argv) > 1 else 512
+seeds = orc.episode_seed(np.arange(n), 0)
+B = [pkg.TetrisBatch(n, 1, 20, 10, seeds=seeds, device=0, split_side=s) for s in (0, 1)]
+stream = torch.cuda.current_stream().cuda_stream
+for b in B:
+    b.set_stream(stream)
+z = lambda: torch.zeros(n, dtype=torch.int32, device="cuda")
+A, Bw = [z(), z()], [z(), z()]
+words = [B[s].split_words(A[s].data_ptr(), A[1 - s].data_ptr(), Bw[0].data_ptr(), Bw[1].data_ptr()) for s in (0, 1)]
+
+
+def step(k):
+    for s in (0, 1):
+        B[s].split_rollout_stage(0, k, out=A[s].data_ptr())
+    B[0].split_rollout_stage(1, k, words=words[0], out=Bw[0].data_ptr())
+    B[1].split_rollout_stage(1, k, words=words[1], out=Bw[1].data_ptr())
+    for s in (0, 1):
+        B[s].split_rollout_stage(2, k, words=words[s])
+
+
+for k in range(64):
+    step(k)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for k in range(64, 64 + steps):
+    step(k)
+e1.record()
+torch.cuda.synchronize()
+us = e0.elapsed_time(e1) * 1e3 / steps
+t0, t1 = B[0].rollout_totals(), B[1].rollout_totals()
+print(json.dumps({"games_per_side": n, "steps": steps, "us_per_step_both_sides_one_gpu": us, "kernels_per_step": 6,
+                  "env_steps_counted": int(t0[0]), "episodes": int(t0[1]), "lines": int(t0[2] + t1[2]), "sent": int(t0[3] + t1[3])}))
