@@ -189,18 +189,9 @@ def main():
     res = shard.run(args.steps, S)                    # exactly K timed launches
     counters, wall, ev_ms = res["counters"], res["wall_s"], res["event_ms"]
     batch = shard
-    chained = (P == 1 or (P == 2 and S == 1 and os.environ.get("TETRIS_NO_DUO") != "1")) and os.environ.get("TETRIS_NO_CHAIN") != "1"
-    unchained = None
-    if chained and S == 1:
-        # reference point, NOT the headline: the same K launches on ONE stream, where every launch waits for the whole previous
-        # one.  This is the per-kernel duration a kernel trace of an unchained run shows (profiles/r02/kernel_stats_p1_s1_unchained.csv).
-        shard.batch.set_chained(False)
-        shard.run(min(args.warmup, 8), S)
-        r2 = shard.run(args.steps, S)
-        shard.batch.set_chained(True)
-        unchained = {"kernel": "k_game<1, M_ROLLOUT>" if P == 1 else "k_duo<M_ROLLOUT>", "launch_us": r2["wall_s"] * 1e6 / args.steps,
-                     "launch_us_events": r2["event_ms"] * 1e3 / args.steps if r2["event_ms"] > 0 else None}
-
+    # chained launches (include/tetris_hip.h: tetris_set_chained): on by default where two launches fit on the device together —
+    # 64k single-player boards do, 64k two-player boards (k_duo needs 220 VGPRs) do not
+    chained = shard.batch.rollout_is_chained(S)
     if rank == 0:
         # env-steps are COUNTED by the step kernels (one increment per game and step in a per-game word, summed by a separate
         # kernel before and after the timed region): the comparison below is a check of the device, not of the host's arithmetic
@@ -213,12 +204,13 @@ def main():
         launch_us_events = ev_ms * 1e3 / args.steps if ev_ms > 0 else None     # (the CPU rehearsal library has no events)
         lib_path = os.path.abspath(os.environ.get("BENCH_LIB_PATH") or ge.LIB)
         roofline = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "kernel": ("k_chain<1>" if P == 1 else "k_duo<M_ROLLOUT, chained>") + " (chained launches: two streams, each wave waits for its own predecessor's epoch word)" if chained
+                    "kernel": "k_chain<1> (chained launches: two streams, each wave waits for its own predecessor's epoch word)" if chained
                               else ("k_duo<M_ROLLOUT>" if (P == 2 and S == 1) else f"k_game<{P}, M_ROLLOUT>"),
                     "launch_us": launch_us, "launch_us_events": launch_us_events, "clock": "wall (same clock as `value`)"}
         if chained:
             roofline["launch_us_is"] = ("the launch PERIOD: consecutive launches overlap (a wave of launch E starts as soon as the same wave of "
-                                        "launch E-1 has published its state), so the durations in a kernel trace are longer than the period")
+                                        "launch E-1 has published its state), so the durations in a kernel trace are longer than the period; "
+                                        "TETRIS_NO_CHAIN=1 puts every launch on one stream (k_game<1, M_ROLLOUT>): profiles/r02/")
         if S == 1:
             algo_bytes = ALGO_BYTES[P] * N                            # per launch, per GPU: SURVEY §8(d) bytes x games
             achieved = algo_bytes / (launch_us * 1e-6) / 1e9
@@ -235,9 +227,6 @@ def main():
                 except Exception:
                     traffic = None
             roofline.update({"traffic": traffic, "traffic_source": source})
-            if unchained:
-                unchained["frac"] = algo_bytes / (unchained["launch_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS
-                roofline["unchained"] = unchained
         else:
             # a fused launch keeps the state in registers for S steps: SURVEY's per-step byte budget does not apply, and a
             # fraction of the HBM roofline would say nothing about it

@@ -56,6 +56,7 @@ _SIGNATURES = {
     "tetris_take_errors": (C.c_int, [C.c_void_p, C.c_void_p]),
     "tetris_set_game_offset": (C.c_int, [C.c_void_p, C.c_uint64]),
     "tetris_set_chained": (C.c_int, [C.c_void_p, C.c_int]),
+    "tetris_rollout_is_chained": (C.c_int, [C.c_void_p, C.c_int]),
     "tetris_reset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "tetris_make_actions": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
     "tetris_finish_actions": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -360,6 +361,12 @@ class TetrisBatch:
     def set_chained(self, on):
         """Chained launches of the built-in rollout on / off (include/tetris_hip.h: tetris_set_chained)."""
         self._check(self.lib.tetris_set_chained(self._h, 1 if on else 0))
+
+    def rollout_is_chained(self, steps_per_launch=1):
+        rc = self.lib.tetris_rollout_is_chained(self._h, int(steps_per_launch))
+        if rc < 0:
+            self._check(rc)
+        return bool(rc)
 
     def set_game_offset(self, first_game_id):
         self._check(self.lib.tetris_set_game_offset(self._h, int(first_game_id)))

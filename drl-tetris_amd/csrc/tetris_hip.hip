@@ -603,6 +603,7 @@ struct tetris_batch {
     uint32_t* d_chain = nullptr;
     uint32_t chain_epoch = 0;
     int use_chain = 1;                   // TETRIS_NO_CHAIN=1 in the environment: every rollout launch on the batch's one stream
+    long long chain_capacity = -1;       // wave slots of the device for the chained kernel (computed on first use)
     bool chain_pending = false;          // chained launches were enqueued since the last drain
     bool home_async = false;             // asynchronous (_dev) work was enqueued on the batch's stream since the last drain
     // Run-ahead gate of the asynchronous entry points: every GATE_GROUP launches an event is recorded; before a new group is
@@ -654,6 +655,24 @@ static int launch_game(tetris_batch* b, const KArgs& a) {
     else hipLaunchKernelGGL((k_game<2, MODE, true>), grid, block, 0, b->stream, a);
     HIP_TRY(hipGetLastError());
     return TETRIS_OK;
+}
+
+// Chained launches are deadlock-free only if the waves of two consecutive launches can be resident together: the waves of
+// launch E spin (in their slots) until the same waves of launch E - 1 have published, so E - 1 must never be short of a slot
+// because of them.  At most two launches are in flight (E + 1 follows E - 1 on the same stream).  The occupancy API can be
+// one workgroup per CU too high for kernels of this SGPR count (MI355X_MICROARCH.md, correctness boundaries): one is
+// subtracted.  64k single-player boards: 1 024 waves per launch, 15 x 256 slots.  64k two-player boards (k_duo, 220
+// VGPRs: 8 waves per CU): 2 048 waves per launch, 7 x 256 slots — does not fit, those launches stay on one stream.
+static bool chain_fits(tetris_batch* b) {
+    if (b->chain_capacity < 0) {
+        int per_cu = 0, cus = 0;
+        const void* fn = b->P == 1 ? (const void*)k_chain<1> : (const void*)k_duo<M_ROLLOUT, true>;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64, 0) != hipSuccess) per_cu = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b->device) != hipSuccess) cus = 0;
+        b->chain_capacity = per_cu > 1 ? (long long)(per_cu - 1) * cus : 0;
+    }
+    const long long waves = b->P == 1 ? ((long long)b->N + CHAIN_LANES - 1) / CHAIN_LANES : ((long long)b->N + 31) / 32;
+    return 2 * waves <= b->chain_capacity;
 }
 
 // Looks at the flag words WITHOUT enqueuing or waiting for anything: answers a pending "extend the RNG tables" request
@@ -1447,6 +1466,17 @@ int tetris_get_actions(tetris_batch* b, const int32_t* idx, int n, const uint8_t
     return result;
 }
 
+static bool rollout_chained(tetris_batch* b, int steps_per_launch) {
+    return b->use_chain && !b->tint && !b->split && b->stream == b->own_stream &&
+           (b->P == 1 || (b->P == 2 && steps_per_launch == 1 && b->use_duo)) && chain_fits(b);
+}
+
+int tetris_rollout_is_chained(tetris_batch* b, int steps_per_launch) {
+    int rc = check_batch(b);
+    if (rc) return rc;
+    return rollout_chained(b, steps_per_launch) ? 1 : 0;
+}
+
 int tetris_rollout_launch(tetris_batch* b, int launches, int steps_per_launch, uint32_t policy_seed, uint64_t first_step,
                           int ms, float* elapsed_ms) {
     int rc = check_batch(b);
@@ -1465,10 +1495,11 @@ int tetris_rollout_launch(tetris_batch* b, int launches, int steps_per_launch, u
     group = group < 1 ? 1 : (group > GATE_GROUP ? GATE_GROUP : group);
     const uint32_t need = (uint32_t)(2 * steps_per_launch * (2 * group + 2) + 16);
     if (b->margin < need) b->margin = need;
-    // single-player batches on their own stream: chained launches (k_chain) — consecutive launches alternate between two
-    // streams and each wave waits for its own predecessor only, not for the slowest wave of the whole previous launch
-    const bool chained = b->use_chain && !b->tint && !b->split && b->stream == b->own_stream &&
-                         (b->P == 1 || (b->P == 2 && steps_per_launch == 1 && b->use_duo));
+    // batches on their own stream: chained launches (k_chain / k_duo<.., true>) — consecutive launches alternate between two
+    // streams and each wave waits for its own predecessor only, not for the slowest wave of the whole previous launch.
+    // Only when TWO launches fit on the device together (chain_fits): a waiting wave keeps its slot, so a launch whose waves
+    // wait must never be able to keep its predecessor's waves from being dispatched.
+    const bool chained = rollout_chained(b, steps_per_launch);
     hipStream_t const home = b->stream;
     if (chained && b->home_async) {
         // both chain streams start behind the asynchronous work the batch's stream still holds (after a synchronous call it

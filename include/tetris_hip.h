@@ -212,8 +212,15 @@ int tetris_rollout_launch(tetris_batch *b, int launches, int steps_per_launch, u
  * alternately and ordered per WAVE — the 64 games of a wave wait, inside the kernel, for an epoch word that the same wave
  * of the previous launch publishes after its state stores have drained — instead of per launch by the stream (where every
  * launch waits for the slowest wave of the whole previous launch plus the kernel boundary).  Results are bit-identical.
+ * A wave that waits keeps its slot; launches are therefore chained only while two of them fit on the device together, and a
+ * wave never waits unboundedly (after ~50 ms it gives up, the call fails with TETRIS_E_HIP and the state is invalid).
  * on = 0: every launch on the batch's one stream.  (Environment: TETRIS_NO_CHAIN=1 sets the default to off.)           */
 int tetris_set_chained(tetris_batch *b, int on);
+/* 1 if tetris_rollout_launch / tetris_rollout_random would chain launches of `steps_per_launch` steps on this batch, 0 if not
+ * (switched off, caller-owned stream, split or colour batch, or two launches do not fit on the device together: a waiting
+ * wave keeps its slot, so chaining is only used where it cannot keep the launch it waits for from being dispatched —
+ * 64k single-player boards fit, 64k two-player boards do not).                                                          */
+int tetris_rollout_is_chained(tetris_batch *b, int steps_per_launch);
 
 /* Global id of this batch's game 0 (default 0): the built-in rollout keys its policy and its
  * reset-seed schedule by global game id, so that N batches on N GPUs simulate N*n_games distinct

@@ -244,6 +244,7 @@ int tetris_take_errors(tetris_batch* b, uint32_t* bits) {
     return TETRIS_OK;
 }
 int tetris_set_chained(tetris_batch*, int) { return TETRIS_OK; }
+int tetris_rollout_is_chained(tetris_batch*, int) { return 0; }
 int tetris_set_game_offset(tetris_batch* b, uint64_t first) { b->game_offset = (uint32_t)first; return TETRIS_OK; }
 
 static int check_idx(tetris_batch* b, const int32_t* idx, int n) {

@@ -103,3 +103,37 @@ def test_batch_independence_and_order_invariance():
     blob = a.snapshot()
     a.restore(blob)
     assert a.snapshot().tobytes() == blob.tobytes()
+
+
+def test_chained_launches_bit_exact_and_only_where_two_launches_fit():
+    """Chained rollout launches (tetris_set_chained: two streams, per-wave epoch words) against the oracle, switching the mode
+    back and forth in one batch; the library chains only where two launches fit on the device together."""
+    n = 65536
+    seeds = orc.episode_seed(np.arange(n), 0)
+    eng = engines.make("hip", n, 1, seeds=seeds)
+    ref = engines.make("oracle", n, 1, seeds=seeds)
+    assert eng.rollout_is_chained(1) and eng.rollout_is_chained(8)
+    total = np.zeros(4, np.uint64)
+    step = 0
+    for chained, launches, fused in ((True, 50, 1), (False, 30, 1), (True, 5, 8), (True, 40, 1), (False, 3, 8), (True, 31, 1)):
+        eng.set_chained(chained)
+        assert eng.rollout_is_chained(fused) == chained
+        c, _ = eng.rollout_random(launches, fused, first_step=step)
+        total += c
+        step += launches * fused
+    _, want = ref.rollout_random(step, threads=min(32, len(os.sched_getaffinity(0))))
+    assert total.tolist() == want.tolist()
+    for lo in range(0, n, 8192):
+        engines.assert_same_state(eng, ref, idx=np.arange(lo, lo + 8192, dtype=np.int32), where=f"games {lo}..")
+    # two-player boards: the duo kernel needs 220 VGPRs, two launches of 64k games do not fit together -> not chained; 8k games do
+    big = engines.make("hip", n, 2, seeds=seeds)
+    assert not big.rollout_is_chained(1)
+    m = 8192
+    small, sref = engines.make("hip", m, 2, seeds=seeds[:m]), engines.make("oracle", m, 2, seeds=seeds[:m])
+    assert small.rollout_is_chained(1) and not small.rollout_is_chained(4)
+    c1, _ = small.rollout_random(150, 1)
+    small.set_chained(False)
+    c2, _ = small.rollout_random(50, 1, first_step=150)
+    _, want = sref.rollout_random(200, threads=8)
+    assert (c1 + c2).tolist() == want.tolist()
+    engines.assert_same_state(small, sref, where="two-player, chained then not")
