@@ -98,6 +98,28 @@ TE_HD void st_agent(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC
 TE_HD uint32_t ld_agent(const uint32_t* p) { return *p; }
 TE_HD void st_agent(uint32_t* p, uint32_t v) { *p = v; }
 #endif
+// On the GPU these are BUFFER accesses: the (wave-uniform) row base goes into a buffer resource in SGPRs, the row offset
+// `word_off * 4` into the instruction's scalar offset and the lane's byte offset into its vector offset — one scalar add per
+// access.  (As global_load/store the same accesses cost a 64-bit scalar add pair or, for about half of them, 64-bit VECTOR
+// address arithmetic: ~75 instructions of a ~1000-instruction step.)  Cache policy bits of the instruction: nt for streamed
+// state, sc1 for agent-scope hand-offs.  Requires the state allocation to stay below 4 GiB (checked by tetris_create).
+#if defined(__HIP_DEVICE_COMPILE__)
+// (stride 0, unbounded num_records: offsets are validated by the host; 0x00020000 = raw 32-bit data format of gfx90a/94x/950)
+TE_HD __amdgpu_buffer_rsrc_t te_rsrc(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), (short)0, -1, 0x00020000);
+}
+constexpr int TE_AUX_NT = 2, TE_AUX_SC1 = 16;     // cache-policy bits of the buffer instructions on gfx940+
+TE_HD uint32_t ldw(const uint32_t* base, uint32_t o, size_t word_off, int mem = MEM_STREAM) {
+    const __amdgpu_buffer_rsrc_t r = te_rsrc(base);
+    if (mem == MEM_AGENT) return __builtin_amdgcn_raw_buffer_load_b32(r, (int)o, (int)(uint32_t)(word_off * 4u), TE_AUX_SC1);
+    return __builtin_amdgcn_raw_buffer_load_b32(r, (int)o, (int)(uint32_t)(word_off * 4u), TE_LD_NT ? TE_AUX_NT : 0);
+}
+TE_HD void stw(uint32_t* base, uint32_t o, size_t word_off, uint32_t v, int mem = MEM_STREAM) {
+    const __amdgpu_buffer_rsrc_t r = te_rsrc(base);
+    if (mem == MEM_AGENT) __builtin_amdgcn_raw_buffer_store_b32(v, r, (int)o, (int)(uint32_t)(word_off * 4u), TE_AUX_SC1);
+    else __builtin_amdgcn_raw_buffer_store_b32(v, r, (int)o, (int)(uint32_t)(word_off * 4u), TE_ST_NT ? TE_AUX_NT : 0);
+}
+#else
 TE_HD uint32_t ldw(const uint32_t* base, uint32_t o, size_t word_off, int mem = MEM_STREAM) {
     const uint32_t* p = (const uint32_t*)((const char*)(base + word_off) + o);
     return mem == MEM_AGENT ? ld_agent(p) : ld_stream(p);
@@ -106,6 +128,7 @@ TE_HD void stw(uint32_t* base, uint32_t o, size_t word_off, uint32_t v, int mem 
     uint32_t* p = (uint32_t*)((char*)(base + word_off) + o);
     if (mem == MEM_AGENT) st_agent(p, v); else st_stream(p, v);
 }
+#endif
 #if defined(__HIP_DEVICE_COMPILE__)
 TE_HD void add_word(uint32_t* p, uint32_t v) { (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 #else
@@ -384,6 +407,16 @@ TE_HD bool fits_at(const Ctx& cx, const Player& q, uint32_t shape, int x, int y)
     return fits_band(band_window(cx, q, y), shape, x);
 }
 
+// The same test for a piece in the spawn column (x = 3, where every new piece appears and where it still is when the tick of
+// the same step runs): only board columns 3..6 can collide — four ANDs instead of a band window over ten columns.
+TE_HD bool fits_spawn_col(const Ctx& cx, const Player& q, uint32_t shape, int y) {
+    constexpr int X0 = (NCOL - 4) / 2;
+    uint32_t hit = 0;
+    TE_UNROLL
+    for (int gx = 0; gx < 4; gx++) hit |= (q.col[X0 + gx] | cx.floor_bits) & (((shape >> (4 * gx)) & 0xFu) << y);
+    return hit == 0;
+}
+
 // dynamic column read without dynamic register indexing
 TE_HD uint32_t col_at(const Player& q, int i) {
     uint32_t a0 = (i & 1) ? q.col[1] : q.col[0];
@@ -644,7 +677,7 @@ TE_HD bool spawn_next(const Ctx& cx, Player& q, uint32_t seed16, uint32_t& statu
         q.pf_ok = 0;
     }
     uint32_t shape = shape_of(cx, q.kind, q.rot);
-    if (!fits_at(cx, q, shape, q.x, 0)) { stamp(cx, q, shape); TE_COUNT(PC_DEATH_SPAWN); return true; }
+    if (!fits_spawn_col(cx, q, shape, 0)) { stamp(cx, q, shape); TE_COUNT(PC_DEATH_SPAWN); return true; }
     return false;
 }
 
@@ -678,8 +711,12 @@ TE_HD int settle(const Ctx& cx, Player& q, uint32_t seed16, uint32_t& status) {
 }
 
 // gamePlay.cpp:61-69 GamePlay::mDown (+ DropDelay.cpp:23-26 reset, :37-41 set)
+// A piece in the spawn column takes the four-column test: that is the piece of nearly every tick (it follows the spawn of the
+// same step; the exception is a player whose loop-1 pass was skipped because an earlier player died in it), so the band-window
+// path usually runs for no lane of a wave.
 TE_HD bool soft_drop(const Ctx& cx, Player& q) {
-    if (fits_at(cx, q, shape_of(cx, q.kind, q.rot), q.x, q.y + 1)) {
+    const uint32_t shape = shape_of(cx, q.kind, q.rot);
+    if (q.x == (NCOL - 4) / 2 ? fits_spawn_col(cx, q, shape, q.y + 1) : fits_at(cx, q, shape, q.x, q.y + 1)) {
         q.y++;
         q.drop_time = q.time_ms;
         q.lock_armed = 0;
@@ -729,23 +766,30 @@ TE_HD int tick(const Ctx& cx, Player& q, int ms, uint32_t seed16, uint32_t& stat
     return 0;                                        // diagnostic build: no timers / garbage / combo
 #endif
     if (gravity_due(q, q.time_ms)) soft_drop(cx, q);
+    // Single exit on purpose: with an early `return settle(..)` the compiler kept the board in different registers on the two
+    // paths and merged them with ~50 register moves that every wave executed every step.
+    int sent = 0;
+    bool finished = false;
     if (q.lock_armed && q.time_ms > q.lock_time && !soft_drop(cx, q)) {    // DropDelay.cpp:43-48
         TE_COUNT(PC_TIMER_LOCK);
         lock_piece(cx, q);                                                  // gamePlay.cpp:38-46 hd
-        return settle(cx, q, seed16, status);
+        sent = settle(cx, q, seed16, status);                               // "return" of the reference: nothing else happens this tick
+        finished = true;
     }
-    if (cx.queue) {
-        int whole = 0;
-        while (q.incoming >= 1.0f) { whole++; q.incoming = q.incoming - 1.f; }
-        if (whole) q_add(q, whole, q.time_ms, status);
+    if (!finished) {
+        if (cx.queue) {
+            int whole = 0;
+            while (q.incoming >= 1.0f) { whole++; q.incoming = q.incoming - 1.f; }
+            if (whole) q_add(q, whole, q.time_ms, status);
+        }
+        sent = combo_expire(cx, q, q.time_ms);
+        if (sent) {
+            if (cx.queue) sent = q_block(q, sent, q.time_ms, false);
+            q.lines_sent = (q.lines_sent + (uint32_t)sent) & 0xFFFFu;
+        }
+        if (cx.queue && q_release(q, q.time_ms))
+            if (push_garbage(cx, q, seed16, status)) sent = -1;
     }
-    int sent = combo_expire(cx, q, q.time_ms);
-    if (sent) {
-        if (cx.queue) sent = q_block(q, sent, q.time_ms, false);
-        q.lines_sent = (q.lines_sent + (uint32_t)sent) & 0xFFFFu;
-    }
-    if (cx.queue && q_release(q, q.time_ms))
-        if (push_garbage(cx, q, seed16, status)) return -1;
     return sent;
 }
 
@@ -1295,24 +1339,28 @@ TE_HD int finish_game(const Ctx& cx, Game<P>& g, int ms) {
     TE_UNROLL
     for (int p = 0; p < P; p++) {
         Player& q = g.pl[p];
-        if (stop || q.dead) continue;
-        int sent = settle(cx, q, g.seed16, g.status);
-        if (sent == -1) { q.dead = 1; stop = true; continue; }     // the reference breaks out of loop 1
-        if (sent) share_lines<P>(g, p, sent);
+        if (!stop && !q.dead) {
+            const int sent = settle(cx, q, g.seed16, g.status);
+            if (sent == -1) { q.dead = 1; stop = true; }           // the reference breaks out of loop 1
+            else if (sent) share_lines<P>(g, p, sent);
+        }
     }
     TE_STAMP(6);
     int alive = 0;
     TE_UNROLL
     for (int p = 0; p < P; p++) {
         Player& q = g.pl[p];
-        if (q.dead) continue;
-        int sent = tick(cx, q, ms, g.seed16, g.status);
-        if (sent == -1) { q.dead = 1; continue; }
-        if (sent) share_lines<P>(g, p, sent);
-        alive++;
-        q.reward = (int)((q.lines_cleared - q.lines_seen) & 0xFFu);
-        q.lines_seen = q.lines_cleared;
-        q.inc_count = cx.queue ? (q_total(q) & 255) : 0;
+        if (!q.dead) {
+            const int sent = tick(cx, q, ms, g.seed16, g.status);
+            if (sent == -1) q.dead = 1;
+            else {
+                if (sent) share_lines<P>(g, p, sent);
+                alive++;
+                q.reward = (int)((q.lines_cleared - q.lines_seen) & 0xFFu);
+                q.lines_seen = q.lines_cleared;
+                q.inc_count = cx.queue ? (q_total(q) & 255) : 0;
+            }
+        }
     }
     if (confine_errors<P>(g)) { g.round_over = 1; return 1; }
     if ((P > 1 && alive < 2) || !alive) { g.round_over = 1; return 1; }

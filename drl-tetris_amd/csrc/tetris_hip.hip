@@ -77,15 +77,19 @@ __global__ __launch_bounds__(64) void k_chain(KArgs a) {
     // the policy draw of this step depends on kernel arguments only: its 40 dependent multiplies run while the wave waits
     if (active) policy_draw(a, (uint32_t)i, a.first_step, g.draw0, g.draw1);
     const uint32_t d0 = g.draw0, d1 = g.draw1;
+#if !defined(TE_CHAIN_EXP) || TE_CHAIN_EXP < 2         // (timing experiments, results invalid: 1 = publish without draining the stores, 2 = no waiting at all)
     if (!chain_wait(a, (uint32_t)wave)) {
         if (lane == 0) { ((volatile uint32_t*)a.status)[F_CHAIN] = 1u; st_agent(a.chain + wave, CHAIN_POISON); }
         return;
     }
+#endif
     if (active) { load_game<P>(geo_of(a), (size_t)i, g, false, P > 1, true, MEM_AGENT, CHAIN_LANES == 64); g.draw0 = d0; g.draw1 = d1; }
     s_shapes[lane] = shape_word;
     __builtin_amdgcn_wave_barrier();
     if (active) game_run<P, M_ROLLOUT, false, MEM_AGENT>(a, i, s_shapes, g, cnt);
+#if !defined(TE_CHAIN_EXP)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every store (and counter atomic) of this wave has been acknowledged
+#endif
     if (lane == 0) st_agent(a.chain + wave, a.epoch);
 }
 
@@ -126,7 +130,13 @@ __global__ __launch_bounds__(256) void k_duo(KArgs a) {
     constexpr int MEM = CHAIN ? MEM_AGENT : MEM_STREAM;
     Geo geo = geo_of(a);
     geo.P = 2;                           // compile-time stride factor for the hot loads
-    const Ref gr = game_ref(geo, (size_t)gi, true), br = board_ref(geo, side, (size_t)gi);     // the wave's 32 games lie in one tile
+    const Ref gr = game_ref(geo, (size_t)gi, true);
+#if TE_TILED
+    const Ref br = board_ref(geo, side, (size_t)gi);
+#else
+    // one UNIFORM row base for both half-waves (it becomes a buffer resource): the player's offset goes into the lane offset
+    const Ref br = {geo.state, (uint32_t)((size_t)side * geo.stride + (size_t)gi) * 4u, 2 * geo.stride};
+#endif
     Game<1> g;
     Player& q = g.pl[0];
     uint32_t pd0 = 0, pd1 = 0;
@@ -833,8 +843,8 @@ static int create_impl(tetris_batch** out, int n_games, int n_players, int heigh
     *out = nullptr;
     if (n_games < 1) return fail(TETRIS_E_ARG, "n_games must be >= 1");
     if (n_players != 1 && n_players != 2) return fail(TETRIS_E_ARG, "n_players must be 1 or 2");
-    if (((long long)n_games + 4096) * n_players > (1ll << 30))       // one row of a state word stays below 4 GiB (32-bit lane offsets)
-        return fail(TETRIS_E_ARG, "n_games * n_players must be <= 2^30");
+    if ((long long)n_games * n_players > (1ll << 23))       // the state allocation stays below 4 GiB (32-bit buffer offsets): 8M boards x 69 words
+        return fail(TETRIS_E_ARG, "n_games * n_players must be <= 2^23");
     if (height < 4 || height > MAX_H) return fail(TETRIS_E_ARG, "height must be in [4, 31]");
     if (width != NCOL) return fail(TETRIS_E_ARG, "width must be 10 (the reference hard-codes 10, gamePlay.cpp:202)");
     if (!piece_map) return fail(TETRIS_E_ARG, "piece_map is NULL");
