@@ -77,19 +77,15 @@ __global__ __launch_bounds__(64) void k_chain(KArgs a) {
     // the policy draw of this step depends on kernel arguments only: its 40 dependent multiplies run while the wave waits
     if (active) policy_draw(a, (uint32_t)i, a.first_step, g.draw0, g.draw1);
     const uint32_t d0 = g.draw0, d1 = g.draw1;
-#if !defined(TE_CHAIN_EXP) || TE_CHAIN_EXP < 2         // (timing experiments, results invalid: 1 = publish without draining the stores, 2 = no waiting at all)
     if (!chain_wait(a, (uint32_t)wave)) {
         if (lane == 0) { ((volatile uint32_t*)a.status)[F_CHAIN] = 1u; st_agent(a.chain + wave, CHAIN_POISON); }
         return;
     }
-#endif
     if (active) { load_game<P>(geo_of(a), (size_t)i, g, false, P > 1, true, MEM_AGENT, CHAIN_LANES == 64); g.draw0 = d0; g.draw1 = d1; }
     s_shapes[lane] = shape_word;
     __builtin_amdgcn_wave_barrier();
     if (active) game_run<P, M_ROLLOUT, false, MEM_AGENT>(a, i, s_shapes, g, cnt);
-#if !defined(TE_CHAIN_EXP)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every store (and counter atomic) of this wave has been acknowledged
-#endif
     if (lane == 0) st_agent(a.chain + wave, a.epoch);
 }
 
@@ -406,10 +402,6 @@ __global__ __launch_bounds__(ENUM_BLOCK) void k_enumerate(Geo geo, int n, const 
     }
     __syncthreads();
     if (!live) return;
-#if defined(TE_ENUM_EXP) && TE_ENUM_EXP == 1
-    if (pre[PRE_BAND] == 12345u) valid[0] = 1;      // experiment: precompute only
-    return;
-#endif
     const size_t boards = (size_t)n;
     const ColumnCtx cc = enum_column(pre, j);
     uint32_t board[NCOL];                                   // the board's columns, read once for the four afterstates
@@ -419,21 +411,13 @@ __global__ __launch_bounds__(ENUM_BLOCK) void k_enumerate(Geo geo, int n, const 
     for (int r = 0; r < 4; r++) {
         const Placement pl = enum_place(pre, cc, s_shapes, H, r);
         const size_t t = PLANAR ? ((size_t)r * boards + i) * 10 + j : ((size_t)i * 4 + r) * 10 + j;
-#if defined(TE_ENUM_EXP) && TE_ENUM_EXP == 3
-        if (pl.ok + pl.y + pl.cleared == 12345) valid[t] = 1;      // experiment: no byte stores
-#else
         valid[t] = (uint8_t)pl.ok;
         land_y[t] = (int8_t)pl.y;
         cleared[t] = (uint8_t)pl.cleared;
-#endif
         if (after) {
             for (int c = 0; c < NCOL; c++) {
                 const uint32_t v = enum_after_col(board[c], pl, c);
-#if defined(TE_ENUM_PLAIN)
-                if (PLANAR) after[((size_t)c * 4 + r) * boards * 10 + (size_t)i * 10 + j] = v;
-#else
                 if (PLANAR) __builtin_nontemporal_store(v, &after[((size_t)c * 4 + r) * boards * 10 + (size_t)i * 10 + j]);
-#endif
                 else after[t * NCOL + c] = v;             // 40 contiguous bytes per lane: left to the L2 to merge
             }
         }
