@@ -321,7 +321,8 @@ __global__ __launch_bounds__(BLOCK) void k_observe_packed(Geo geo, int n, const 
     const int i = blockIdx.x * BLOCK + threadIdx.x;
     const int first = blockIdx.x * BLOCK;
     const int nb = (n - first < BLOCK) ? n - first : BLOCK;
-    for (int sl = 0; sl < P; sl++) {
+    {
+        const int sl = blockIdx.y;                       // one workgroup per (64 boards, slot): twice the waves in flight for P = 2
         if (i < n) {
             const size_t slot = safe_slot(idx, i, (int)geo.n_games);
             const int me = safe_player(player, i, P);
@@ -354,11 +355,23 @@ __global__ __launch_bounds__(BLOCK) void k_observe_packed(Geo geo, int n, const 
         __syncthreads();
         uint32_t* dst = (uint32_t*)(visual + ((size_t)sl * n + first) * (size_t)(H * NCOL));
         const uint32_t words = (uint32_t)nb * (uint32_t)nw;
-        for (uint32_t g = threadIdx.x; g < words; g += BLOCK) {
-            const uint32_t t = __umulhi(g, inv_nw);          // g / nw (exact: g < 2^16, inv_nw = ceil(2^32 / nw))
-            dst[g] = s_words[g + t];
-        }
-        __syncthreads();
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        if ((((uintptr_t)dst) & 15u) == 0) {
+            // the tile leaves as 16-byte streaming stores (a quarter of the store instructions); the four words of a store may
+            // straddle a board's row in the padded LDS tile, so each is fetched by its own index
+            for (uint32_t g = 4u * threadIdx.x; g < words; g += 4u * BLOCK) {
+                u32x4 v;
+                v.x = s_words[g + __umulhi(g, inv_nw)];      // g / nw (exact: g < 2^16, inv_nw = ceil(2^32 / nw))
+                if (g + 3u < words) {
+                    v.y = s_words[g + 1u + __umulhi(g + 1u, inv_nw)];
+                    v.z = s_words[g + 2u + __umulhi(g + 2u, inv_nw)];
+                    v.w = s_words[g + 3u + __umulhi(g + 3u, inv_nw)];
+                    __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(dst + g));
+                } else
+                    for (uint32_t k = g; k < words; k++) dst[k] = s_words[k + __umulhi(k, inv_nw)];
+            }
+        } else
+            for (uint32_t g = threadIdx.x; g < words; g += BLOCK) dst[g] = s_words[g + __umulhi(g, inv_nw)];
     }
 }
 
@@ -1225,7 +1238,7 @@ int tetris_observe_packed_dev(tetris_batch* b, const int32_t* d_idx, int n, cons
         const int nw = b->H * NCOL / 4;
         const size_t lds = (size_t)OB * (nw + 1) * 4;
         const uint32_t inv_nw = (uint32_t)(((1ull << 32) + (uint64_t)nw - 1) / (uint64_t)nw);
-        dim3 ogrid((unsigned)((n + OB - 1) / OB)), oblock(OB);
+        dim3 ogrid((unsigned)((n + OB - 1) / OB), (unsigned)b->P), oblock(OB);
         if (b->P == 1)
             hipLaunchKernelGGL((k_observe_packed<1, OB>), ogrid, oblock, lds, b->stream, geo_of_batch(b), n, d_idx, d_player, b->H,
                                d_visual, d_vector, d_piece, inv_nw);

@@ -14,8 +14,8 @@ mod = importlib.import_module("drl-tetris_amd.distributed")
 P = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 sh = mod.ShardedRollout(65536, P, 20, 10, rank=0, world=1, device=0)
 sh.run(64, 1)
-for rep in range(2):
-    for chained in (True, False, True):
+for rep in range(3):
+    for chained in (True, True, False, False):
         sh.batch.set_chained(chained)
         sh.run(8, 1)
         r = sh.run(2048, 1)

@@ -26,6 +26,7 @@ for c in enum_planar enum_rows enum_noafter_planar observe step_auto_1p step_aut
   timeout -k 10 200 python profiles/kernel_prof.py $c > $O/kernel_$c.json 2>/dev/null
   prof prof_$c $R/profiles/kernel_prof.py $c
 done
+python profiles/order_check.py 1 > $O/order_check.txt 2>&1
 timeout -k 10 200 python profiles/split_stages.py > $O/split_stages.json 2>/dev/null
 prof prof_split $R/profiles/split_stages.py 256
 profiles/pmc_passes.sh $O/pmc_p1 all bench.py --cpu-seconds 0 --steps 256 --warmup 16 > $O/pmc_p1.txt 2>&1
