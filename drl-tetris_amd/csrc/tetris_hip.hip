@@ -610,6 +610,7 @@ struct tetris_batch {
     uint32_t* d_chain = nullptr;
     uint32_t chain_epoch = 0;
     int use_chain = 1;                   // TETRIS_NO_CHAIN=1 in the environment: every rollout launch on the batch's one stream
+    int use_graph = 0;                   // TETRIS_GRAPH=1: un-chained rollout launches replayed from HIP graphs (profiling aid)
     long long chain_capacity = -1;       // wave slots of the device for the chained kernel (computed on first use)
     bool chain_pending = false;          // chained launches were enqueued since the last drain
     bool home_async = false;             // asynchronous (_dev) work was enqueued on the batch's stream since the last drain
@@ -861,6 +862,7 @@ static int create_impl(tetris_batch** out, int n_games, int n_players, int heigh
     b->tint = (flags & TETRIS_FLAG_COLOURS) ? 1 : 0;
     { const char* e = getenv("TETRIS_NO_DUO"); b->use_duo = !(e && e[0] == '1'); }
     { const char* e = getenv("TETRIS_NO_CHAIN"); b->use_chain = !(e && e[0] == '1'); }
+    { const char* e = getenv("TETRIS_GRAPH"); b->use_graph = (e && e[0] == '1'); }
     b->nw = b->tint ? NWORDS_TINT : NWORDS;
 #define CREATE_TRY(expr)                                                                    \
     do {                                                                                    \
@@ -1508,6 +1510,40 @@ int tetris_rollout_launch(tetris_batch* b, int launches, int steps_per_launch, u
     // wait must never be able to keep its predecessor's waves from being dispatched.
     const bool chained = rollout_chained(b, steps_per_launch);
     hipStream_t const home = b->stream;
+    if (!chained && b->use_graph && steps_per_launch >= 1) {
+        // TETRIS_GRAPH=1 (profiling aid): the launches are captured into HIP graphs of up to 128 kernel nodes and replayed, so the
+        // host makes one call per 128 launches.  Under rocprofv3 a plain launch costs the host ~8 us — more than the kernel
+        // takes — and the kernels of a profiled run are then no longer back to back; replayed from a graph they are.
+        HIP_TRY(hipEventRecord(b->ev0, home));
+        for (int l0 = 0; l0 < launches; l0 += 128) {
+            const int m = launches - l0 < 128 ? launches - l0 : 128;
+            if ((rc = gate_launch(b, 1))) return rc;                      // flags are looked at between graphs: the margin below covers 128 launches
+            const uint32_t keep = b->margin;
+            if (b->margin < (uint32_t)(2 * steps_per_launch * 3 * 128 + 16)) b->margin = (uint32_t)(2 * steps_per_launch * 3 * 128 + 16);
+            hipGraph_t graph = nullptr;
+            hipGraphExec_t exec = nullptr;
+            HIP_TRY(hipStreamBeginCapture(home, hipStreamCaptureModeThreadLocal));
+            for (int l = l0; l < l0 + m && !rc; l++) {
+                KArgs a = base_args(b, b->N, nullptr);
+                a.ms = ms; a.steps = steps_per_launch; a.policy_seed = policy_seed;
+                a.first_step = first_step + (uint64_t)l * (uint64_t)steps_per_launch;
+                rc = launch_game<M_ROLLOUT>(b, a);
+            }
+            b->margin = keep;
+            const hipError_t ce = hipStreamEndCapture(home, &graph);
+            if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+            HIP_TRY(ce);
+            HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+            const hipError_t le = hipGraphLaunch(exec, home);
+            const hipError_t se = hipStreamSynchronize(home);          // (the graph objects must outlive the launch)
+            (void)hipGraphExecDestroy(exec); (void)hipGraphDestroy(graph);
+            HIP_TRY(le); HIP_TRY(se);
+        }
+        HIP_TRY(hipEventRecord(b->ev1, home));
+        if ((rc = finish_call(b))) return rc;
+        if (elapsed_ms) HIP_TRY(hipEventElapsedTime(elapsed_ms, b->ev0, b->ev1));
+        return TETRIS_OK;
+    }
     if (chained && b->home_async) {
         // both chain streams start behind the asynchronous work the batch's stream still holds (after a synchronous call it
         // is empty and nothing has to be ordered)

@@ -8,6 +8,8 @@ mkdir -p $DST
 cp $SRC/bench_p1_s1.json $SRC/bench_p1_s1_driver_flags.json $SRC/bench_p2_s1.json $SRC/bench_p1_s32.json $SRC/bench_configs.json $SRC/split_stages.json $DST/
 for c in enum_planar enum_rows enum_noafter_planar observe step_auto_1p step_auto_2p; do cp $SRC/kernel_$c.json $DST/; done
 cp $SRC/pytest_gpu.log $DST/pytest_gpu.txt
+cp $SRC/prof_p1.log $DST/bench_under_profiler_p1_s1.txt
+cp $SRC/prof_p1_unchained.log $DST/bench_under_profiler_p1_s1_unchained.txt
 [ -f $SRC/order_check.txt ] && cp $SRC/order_check.txt profiles/r02/order_check.txt
 newest() { ls -t $(find "$1" -name "$2") | head -1; }
 cp "$(newest $SRC/prof_p1 '*kernel_stats.csv')" $DST/kernel_stats_p1_s1.csv

@@ -18,10 +18,12 @@ R=$GRAFT_REPO_ROOT
 prof() { (cd /tmp; export TMPDIR=/tmp; timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/$1 -- python3 "${@:2}" > $R/$O/$1.log 2>&1); }
 prof prof_p1 $R/bench.py --cpu-seconds 0
 prof prof_p2 $R/bench.py --cpu-seconds 0 --players 2
-export TETRIS_NO_CHAIN=1
+# one stream, launches replayed from HIP graphs (TETRIS_GRAPH=1): under the profiler a plain launch costs the host ~8 us, more
+# than the kernel takes; from a graph the kernels of the profiled run are back to back like those of the un-profiled one
+export TETRIS_NO_CHAIN=1 TETRIS_GRAPH=1
 prof prof_p1_unchained $R/bench.py --cpu-seconds 0
 prof prof_p2_unchained $R/bench.py --cpu-seconds 0 --players 2
-unset TETRIS_NO_CHAIN
+unset TETRIS_NO_CHAIN TETRIS_GRAPH
 for c in enum_planar enum_rows enum_noafter_planar observe step_auto_1p step_auto_2p; do
   timeout -k 10 200 python profiles/kernel_prof.py $c > $O/kernel_$c.json 2>/dev/null
   prof prof_$c $R/profiles/kernel_prof.py $c
