@@ -303,7 +303,7 @@ class TetrisBatch:
 
     def enumerate_drops_dev(self, n, valid, land_y, cleared, after=None, idx=None, player=None, planar=False):
         """tetris_enumerate_drops_dev_ex: raw DEVICE addresses (int / c_void_p) or None; only enqueues.
-        planar: rotation-major outputs — valid / land_y / cleared [4][n][10], after [10][4][n][10]."""
+        planar: rotation-minor planes — valid / land_y / cleared [n][10][4], after [10][n][10][4]."""
         self._check(self.lib.tetris_enumerate_drops_dev_ex(self._h, idx, int(n), player, valid, land_y, cleared, after, 1 if planar else 0))
 
     def get_actions(self, idx=None, player=None, max_lists=64, max_keys=48):

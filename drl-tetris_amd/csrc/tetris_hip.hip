@@ -379,8 +379,9 @@ __global__ __launch_bounds__(BLOCK) void k_observe_packed(Geo geo, int n, const 
 // rotations in turn.  Phase A: a board's ten lanes fetch its ten columns (ONE global load per word and board) and its piece
 // word.  Phase B: they fill its BoardPre in LDS (tetris_kernels.h): band window (LDS atomics), depth strip (byte writes), prefix /
 // suffix ANDs.  Phase C: four placements per lane from ~10 LDS reads each.  16 384 boards = 2 560 waves, all resident at once.
-// PLANAR: every output is rotation-major — valid / land_y / cleared [4][n][10], after [10][4][n][10] — so that each store of a
-// wave is 64 consecutive elements; else the layouts tetris_enumerate_drops documents ([n][4][10] and [n][4][10][10]).
+// PLANAR: rotation-minor planes — valid / land_y / cleared [n][10][4], after [10][n][10][4] (column plane c, game, column index,
+// rotation) — so that a lane's four placements are one 4-byte / 16-byte store; else the layouts tetris_enumerate_drops documents
+// ([n][4][10] and [n][4][10][10]).
 template <int P, bool PLANAR>
 __global__ __launch_bounds__(ENUM_BLOCK) void k_enumerate(Geo geo, int n, const int32_t* idx, const uint8_t* player, int H,
                                                           uint8_t* valid, int8_t* land_y, uint8_t* cleared, uint32_t* after) {
@@ -415,24 +416,48 @@ __global__ __launch_bounds__(ENUM_BLOCK) void k_enumerate(Geo geo, int n, const 
     }
     __syncthreads();
     if (!live) return;
-    const size_t boards = (size_t)n;
     const ColumnCtx cc = enum_column(pre, j);
-    uint32_t board[NCOL];                                   // the board's columns, read once for the four afterstates
-    if (after)
-        for (int c = 0; c < NCOL; c++) board[c] = pre[PRE_COL + c];
-    TE_UNROLL
-    for (int r = 0; r < 4; r++) {
-        const Placement pl = enum_place(pre, cc, s_shapes, H, r);
-        const size_t t = PLANAR ? ((size_t)r * boards + i) * 10 + j : ((size_t)i * 4 + r) * 10 + j;
-        valid[t] = (uint8_t)pl.ok;
-        land_y[t] = (int8_t)pl.y;
-        cleared[t] = (uint8_t)pl.cleared;
+    if (PLANAR) {
+        // rotation-minor planes: the lane's four placements are adjacent, so each result array takes ONE 4-byte store per lane and
+        // each afterstate column ONE 16-byte store (13 stores per lane instead of 52; a wave's store = 1 KB contiguous)
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        Placement pl[4];
+        uint32_t v_ok = 0, v_y = 0, v_cl = 0;
+        TE_UNROLL
+        for (int r = 0; r < 4; r++) {
+            pl[r] = enum_place(pre, cc, s_shapes, H, r);
+            v_ok |= (uint32_t)pl[r].ok << (8 * r);
+            v_y |= ((uint32_t)pl[r].y & 0xFFu) << (8 * r);
+            v_cl |= (uint32_t)pl[r].cleared << (8 * r);
+        }
+        const size_t t4 = (size_t)i * 10 + j;                     // element (game i, column index j) of the [n][10][4] arrays
+        reinterpret_cast<uint32_t*>(valid)[t4] = v_ok;
+        reinterpret_cast<uint32_t*>(land_y)[t4] = v_y;
+        reinterpret_cast<uint32_t*>(cleared)[t4] = v_cl;
         if (after) {
+            u32x4* out = reinterpret_cast<u32x4*>(after);
+            const size_t plane = (size_t)n * 10;
             for (int c = 0; c < NCOL; c++) {
-                const uint32_t v = enum_after_col(board[c], pl, c);
-                if (PLANAR) __builtin_nontemporal_store(v, &after[((size_t)c * 4 + r) * boards * 10 + (size_t)i * 10 + j]);
-                else after[t * NCOL + c] = v;             // 40 contiguous bytes per lane: left to the L2 to merge
+                const uint32_t bc = pre[PRE_COL + c];
+                u32x4 v;
+                v.x = enum_after_col(bc, pl[0], c); v.y = enum_after_col(bc, pl[1], c);
+                v.z = enum_after_col(bc, pl[2], c); v.w = enum_after_col(bc, pl[3], c);
+                __builtin_nontemporal_store(v, &out[(size_t)c * plane + t4]);
             }
+        }
+    } else {
+        uint32_t board[NCOL];                                   // the board's columns, read once for the four afterstates
+        if (after)
+            for (int c = 0; c < NCOL; c++) board[c] = pre[PRE_COL + c];
+        TE_UNROLL
+        for (int r = 0; r < 4; r++) {
+            const Placement pl = enum_place(pre, cc, s_shapes, H, r);
+            const size_t t = ((size_t)i * 4 + r) * 10 + j;
+            valid[t] = (uint8_t)pl.ok;
+            land_y[t] = (int8_t)pl.y;
+            cleared[t] = (uint8_t)pl.cleared;
+            if (after)
+                for (int c = 0; c < NCOL; c++) after[t * NCOL + c] = enum_after_col(board[c], pl, c);      // 40 contiguous bytes per lane: left to the L2 to merge
         }
     }
 }
@@ -1377,6 +1402,8 @@ int tetris_enumerate_drops_dev_ex(tetris_batch* b, const int32_t* d_idx, int n, 
     if (!d_valid || !d_land_y || !d_cleared) return fail(TETRIS_E_ARG, "valid/land_y/cleared are NULL");
     if (n < 0 || (!d_idx && n > b->N)) return fail(TETRIS_E_ARG, "n out of range");
     if (flags & ~TETRIS_ENUM_PLANAR) return fail(TETRIS_E_ARG, "unknown flag");
+    if ((flags & TETRIS_ENUM_PLANAR) && ((((uintptr_t)d_valid | (uintptr_t)d_land_y | (uintptr_t)d_cleared) & 3u) || ((uintptr_t)d_after & 15u)))
+        return fail(TETRIS_E_ARG, "planar outputs: valid / land_y / cleared must be 4-byte aligned, after 16-byte aligned");
     if (n == 0) return TETRIS_OK;
     b->home_async = true;
     dim3 grid((unsigned)((n + ENUM_BOARDS - 1) / ENUM_BOARDS)), block(ENUM_BLOCK);

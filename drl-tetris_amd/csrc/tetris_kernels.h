@@ -556,7 +556,7 @@ TE_HD uint32_t enum_after_col(uint32_t board_col, const Placement& pl, int c) {
 }
 
 // serial driver of one board's 40 placements (CPU harness)
-// `planar`: rotation-major outputs, valid / land_y / cleared [4][n][10] and after [10][4][n][10] (see k_enumerate)
+// `planar`: rotation-minor planes, valid / land_y / cleared [n][10][4] and after [10][n][10][4] (see k_enumerate)
 template <int P>
 TE_HD void enumerate_body(const Geo& geo, int i, int n, const int32_t* idx, const uint8_t* player, int H,
                           const uint32_t* shapes, uint8_t* valid, int8_t* land_y, uint8_t* cleared, uint32_t* after, bool planar) {
@@ -565,13 +565,13 @@ TE_HD void enumerate_body(const Geo& geo, int i, int n, const int32_t* idx, cons
     for (int r = 0; r < 4; r++)
         for (int xi = 0; xi < NCOL; xi++) {
             const Placement pl = enum_place(pre, enum_column(pre, xi), shapes, H, r);
-            const size_t t = planar ? ((size_t)r * n + i) * 10 + xi : ((size_t)i * 4 + r) * 10 + xi;
+            const size_t t = planar ? ((size_t)i * 10 + xi) * 4 + r : ((size_t)i * 4 + r) * 10 + xi;
             valid[t] = (uint8_t)pl.ok;
             land_y[t] = (int8_t)pl.y;
             cleared[t] = (uint8_t)pl.cleared;
             if (after)
                 for (int c = 0; c < NCOL; c++)
-                    after[planar ? ((size_t)c * 4 + r) * (size_t)n * 10 + (size_t)i * 10 + xi : t * NCOL + c] = enum_after_col(pre[PRE_COL + c], pl, c);
+                    after[planar ? (size_t)c * n * 40 + t : t * NCOL + c] = enum_after_col(pre[PRE_COL + c], pl, c);
         }
 }
 

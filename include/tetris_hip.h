@@ -175,10 +175,12 @@ int tetris_enumerate_drops(tetris_batch *b, const int32_t *idx, int n, const uin
 /* same with device pointers (d_idx / d_player may be NULL), asynchronous on the batch's stream                        */
 int tetris_enumerate_drops_dev(tetris_batch *b, const int32_t *d_idx, int n, const uint8_t *d_player,
                                uint8_t *d_valid, int8_t *d_land_y, uint8_t *d_cleared, uint32_t *d_after);
-/* same with flags.  TETRIS_ENUM_PLANAR: every output is rotation-major — d_valid / d_land_y / d_cleared are [4][n][10] and
- * d_after is [10][4][n][10] (column c of the placement (game i, rotation r, column index xi) at
- * d_after[((c * 4 + r) * n + i) * 10 + xi]) — so that every store of a wavefront is 64 consecutive elements; a consumer
- * that feeds the afterstates to a network reads one (column, rotation) plane at a time.                              */
+/* same with flags.  TETRIS_ENUM_PLANAR: rotation-minor planes — d_valid / d_land_y / d_cleared are [n][10][4] (game, column
+ * index xi, rotation r) and d_after is [10][n][10][4]: column c of the placement (game i, rotation r, column index xi) at
+ * d_after[((c * n + i) * 10 + xi) * 4 + r].  The four rotations of a (game, column) pair are adjacent, so the kernel writes
+ * each result array with one 4-byte store and each afterstate column with one 16-byte store per lane, 1 KB contiguous per
+ * wavefront; a consumer that feeds the afterstates to a network reads one column plane [n][10][4] at a time.
+ * d_valid / d_land_y / d_cleared must be 4-byte aligned, d_after 16-byte aligned.                                      */
 #define TETRIS_ENUM_PLANAR 1
 int tetris_enumerate_drops_dev_ex(tetris_batch *b, const int32_t *d_idx, int n, const uint8_t *d_player,
                                   uint8_t *d_valid, int8_t *d_land_y, uint8_t *d_cleared, uint32_t *d_after, int flags);

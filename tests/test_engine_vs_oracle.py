@@ -358,7 +358,7 @@ def test_enumerate_drops_matches_oracle(kind):
     v1, y1, c1, _ = eng.enumerate_drops(idx=sub, player=1, columns=False)
     v2, y2, c2, _ = ref.enumerate_drops(idx=sub, player=1, cells=False)
     assert np.array_equal(v1, v2) and np.array_equal(y1, y2) and np.array_equal(c1, c2)
-    # device-pointer form, both output layouts (game-major and rotation-major planes), with a ragged last workgroup
+    # device-pointer form, both output layouts (game-major and rotation-minor column planes), with a ragged last workgroup
     D = _DevArrays(kind)
     m = n - 3
     player = rng.integers(0, 2, m).astype(np.uint8)
@@ -368,11 +368,11 @@ def test_enumerate_drops_matches_oracle(kind):
         a_d, p_d = D.put(np.zeros(m * 400, np.uint32).view(np.int32)), D.put(player)
         eng.enumerate_drops_dev(m, D.ptr(v_d), D.ptr(y_d), D.ptr(c_d), D.ptr(a_d), player=D.ptr(p_d), planar=planar)
         eng.sync()
-        shape3 = lambda t: t.reshape(4, m, 10).transpose(1, 0, 2) if planar else t.reshape(m, 4, 10)
+        shape3 = lambda t: t.reshape(m, 10, 4).transpose(0, 2, 1) if planar else t.reshape(m, 4, 10)
         assert np.array_equal(shape3(D.get(v_d)), want[0]) and np.array_equal(shape3(D.get(y_d)), want[1])
         assert np.array_equal(shape3(D.get(c_d)), want[2])
         a = D.get(a_d).view(np.uint32)
-        a = a.reshape(10, 4, m, 10).transpose(2, 1, 3, 0) if planar else a.reshape(m, 4, 10, 10)
+        a = a.reshape(10, m, 10, 4).transpose(1, 3, 2, 0) if planar else a.reshape(m, 4, 10, 10)
         assert np.array_equal(a, want[3]), planar
 
 

@@ -80,6 +80,15 @@ def test_c4_enumerate_16384_boards_at_step_12():
     assert np.array_equal(d_land.cpu().numpy().reshape(n, 4, 10)[ok], y2[ok])
     assert np.array_equal(d_clr.cpu().numpy().reshape(n, 4, 10)[ok], c2[ok])
     assert np.array_equal(d_after.cpu().numpy().view(np.uint32).reshape(n, 4, 10, 10)[ok], a1[ok])
+    # ... and its planar form (rotation-minor column planes: [n][10][4] and [10][n][10][4])
+    for t in (d_valid, d_land, d_clr, d_after):
+        t.zero_()
+    eng.enumerate_drops_dev(n, p(d_valid), p(d_land), p(d_clr), p(d_after), planar=True)
+    eng.sync()
+    assert np.array_equal(d_valid.cpu().numpy().reshape(n, 10, 4).transpose(0, 2, 1), v2)
+    assert np.array_equal(d_land.cpu().numpy().reshape(n, 10, 4).transpose(0, 2, 1)[ok], y2[ok])
+    assert np.array_equal(d_clr.cpu().numpy().reshape(n, 10, 4).transpose(0, 2, 1)[ok], c2[ok])
+    assert np.array_equal(d_after.cpu().numpy().view(np.uint32).reshape(10, n, 10, 4).transpose(1, 3, 2, 0)[ok], a1[ok])
 
 
 def test_batch_independence_and_order_invariance():
