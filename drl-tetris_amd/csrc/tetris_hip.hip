@@ -639,6 +639,7 @@ struct tetris_batch {
     long long chain_capacity = -1;       // wave slots of the device for the chained kernel (computed on first use)
     bool chain_pending = false;          // chained launches were enqueued since the last drain
     bool home_async = false;             // asynchronous (_dev) work was enqueued on the batch's stream since the last drain
+    bool busy = true;                    // something was enqueued on one of the batch's streams since the last drain
     // Run-ahead gate of the asynchronous entry points: every GATE_GROUP launches an event is recorded; before a new group is
     // enqueued the host waits for the event of the group before the previous one.  At most 2 * GATE_GROUP + 1 launches are
     // therefore in flight whose flag words the host has not seen; `margin` is sized for that many steps.
@@ -720,6 +721,7 @@ static int service_flags(tetris_batch* b) {
         if (want >= (uint32_t)b->tab->n_chunks * CHUNK && b->tab->n_chunks < MAX_CHUNKS) {
             int rc = tables_extend(b->tab, b->stream);
             if (rc) return rc;
+            b->busy = true;
         }
         f[F_EXTEND] = 0;
     }
@@ -756,12 +758,18 @@ static hipError_t drain_stream(hipStream_t st) {
 
 // drain the batch's stream(s), then the flag words: sticky errors surface, the RNG tables are extended when a board came close to their end
 static int finish_call(tetris_batch* b) {
+    if (!b->busy && !b->chain_pending && b->stream == b->own_stream) {      // drained already and nothing enqueued since: only the flag words
+        int rc0 = service_flags(b);
+        if (rc0) return rc0;
+        if (!b->busy) return TETRIS_OK;           // (an extension would have enqueued work)
+    }
     if (b->chain_pending) {
         for (int k = 0; k < 2; k++) HIP_TRY(drain_stream(b->chain_stream[k]));
         b->chain_pending = false;
     }
     HIP_TRY(drain_stream(b->stream));
     b->home_async = false;
+    b->busy = false;
     b->gate_count = 0; b->gate_pending[0] = b->gate_pending[1] = 0;
     volatile uint32_t* f = b->flags;
     // (F_EXHAUSTED / F_FIFO: capacity errors are confined to the games they happened in — tetris_take_errors)
@@ -775,9 +783,11 @@ static int finish_call(tetris_batch* b) {
     return TETRIS_OK;
 }
 
-static int check_batch(tetris_batch* b) {
+// every entry point starts here; `enqueues`: the call may put work on one of the batch's streams (all but the pure waits)
+static int check_batch(tetris_batch* b, bool enqueues = true) {
     if (!b) return fail(TETRIS_E_ARG, "null batch");
     HIP_TRY(hipSetDevice(b->device));
+    if (enqueues) b->busy = true;
     return TETRIS_OK;
 }
 
@@ -1033,7 +1043,7 @@ int tetris_rollout_totals(tetris_batch* b, uint64_t totals[4]) {
 }
 
 int tetris_take_errors(tetris_batch* b, uint32_t* bits) {
-    int rc = check_batch(b);
+    int rc = check_batch(b, false);
     if (rc) return rc;
     if (!bits) return fail(TETRIS_E_ARG, "bits is NULL");
     if ((rc = finish_call(b))) return rc;
@@ -1044,7 +1054,7 @@ int tetris_take_errors(tetris_batch* b, uint32_t* bits) {
 }
 
 int tetris_sync(tetris_batch* b) {
-    int rc = check_batch(b);
+    int rc = check_batch(b, false);
     if (rc) return rc;
     return finish_call(b);
 }
@@ -1502,13 +1512,30 @@ int tetris_get_actions(tetris_batch* b, const int32_t* idx, int n, const uint8_t
     return result;
 }
 
+// Chained launches of two batches at once would need room for four launches; only one batch per device chains at a time
+// (another one that comes along meanwhile puts its launches on one stream).
+static std::mutex g_chain_mutex;
+static tetris_batch* g_chain_owner[64] = {nullptr};
+static bool chain_acquire(tetris_batch* b) {
+    std::lock_guard<std::mutex> lock(g_chain_mutex);
+    tetris_batch*& owner = g_chain_owner[b->device & 63];
+    if (owner && owner != b) return false;
+    owner = b;
+    return true;
+}
+static void chain_release(tetris_batch* b) {
+    std::lock_guard<std::mutex> lock(g_chain_mutex);
+    tetris_batch*& owner = g_chain_owner[b->device & 63];
+    if (owner == b) owner = nullptr;
+}
+
 static bool rollout_chained(tetris_batch* b, int steps_per_launch) {
     return b->use_chain && !b->tint && !b->split && b->stream == b->own_stream &&
            (b->P == 1 || (b->P == 2 && steps_per_launch == 1 && b->use_duo)) && chain_fits(b);
 }
 
 int tetris_rollout_is_chained(tetris_batch* b, int steps_per_launch) {
-    int rc = check_batch(b);
+    int rc = check_batch(b, false);
     if (rc) return rc;
     return rollout_chained(b, steps_per_launch) ? 1 : 0;
 }
@@ -1535,7 +1562,11 @@ int tetris_rollout_launch(tetris_batch* b, int launches, int steps_per_launch, u
     // streams and each wave waits for its own predecessor only, not for the slowest wave of the whole previous launch.
     // Only when TWO launches fit on the device together (chain_fits): a waiting wave keeps its slot, so a launch whose waves
     // wait must never be able to keep its predecessor's waves from being dispatched.
-    const bool chained = rollout_chained(b, steps_per_launch);
+    const bool chained = rollout_chained(b, steps_per_launch) && chain_acquire(b);
+    struct ChainGuard {                           // (released on every return path; the call ends with both chain streams drained)
+        tetris_batch* b; bool held;
+        ~ChainGuard() { if (held) chain_release(b); }
+    } chain_guard{b, chained};
     hipStream_t const home = b->stream;
     if (!chained && b->use_graph && steps_per_launch >= 1) {
         // TETRIS_GRAPH=1 (profiling aid): the launches are captured into HIP graphs of up to 128 kernel nodes and replayed, so the
