@@ -87,7 +87,7 @@ TE_HD void report_status(const KArgs& a, uint32_t st) {
 
 // ---- chained launches (tetris_hip.hip: k_chain): the hand-over of a wave's 64 games from launch E - 1 to launch E
 constexpr uint32_t CHAIN_POISON = 0xFFFFFFFFu;      // a wave gave up waiting: every later launch's wave passes the poison on
-constexpr int CHAIN_SPIN_LIMIT = 1 << 18;           // polls before a wave gives up (each followed by a short sleep): ~50 ms
+constexpr int CHAIN_SPIN_LIMIT = 1 << 21;           // polls before a wave gives up (each ~1 us with its short sleep): ~2 s
 
 // true when the state of this wave's games as launch E - 1 left it is visible (their stores were `sc1` and drained before the
 // epoch word was written, and the word is polled with an `sc1` load: MI355X_MICROARCH.md, valid forms of an inter-workgroup hand-off)
