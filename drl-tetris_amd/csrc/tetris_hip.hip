@@ -483,6 +483,8 @@ __global__ __launch_bounds__(256) void k_set_dead(Geo geo, int n, const int32_t*
 
 // ============================================================================ host side
 
+struct tetris_batch;
+static void chain_release(tetris_batch* b);
 static thread_local std::string g_err;
 static int fail(int code, const std::string& msg) {
     g_err = msg;
@@ -852,6 +854,8 @@ void* tetris_stream(tetris_batch* b) { return b ? (void*)b->stream : nullptr; }
 int tetris_destroy(tetris_batch* b) {
     if (!b) return TETRIS_OK;
     (void)hipSetDevice(b->device);
+    for (hipStream_t st : b->chain_stream) if (st) (void)hipStreamSynchronize(st);      // (a call that failed half-way may have left launches there)
+    chain_release(b);
     if (b->stream) (void)hipStreamSynchronize(b->stream);
     if (b->tab) tables_release(b->tab);
     (void)hipFree(b->d_shadow); (void)hipFree(b->d_state); (void)hipFree(b->d_gstate); (void)hipFree(b->d_counters);
