@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Parity of an experiment build of the library (TETRIS_LIB=path): 65 536 single-player boards, 64 chained single-step launches
+"""Parity of an experiment build of the library (TETRIS_LIB=path): 65 536 boards (argv[1] players each), 64 chained single-step launches
 + 4 fused ones, counters and every board against the oracle on all host cores."""
 import os
 import sys
@@ -13,9 +13,11 @@ from tests import engines
 
 pkg = ge.package()
 n = 65536
+P = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 seeds = orc.episode_seed(np.arange(n), 0)
-eng = pkg.TetrisBatch(n, 1, 20, 10, seeds=seeds, device=0, lib_path=os.environ.get("TETRIS_LIB"))
-ref = orc.OracleBatch(n, 1, 20, 10, seeds=seeds)
+eng = pkg.TetrisBatch(n, P, 20, 10, seeds=seeds, device=0, lib_path=os.environ.get("TETRIS_LIB"))
+ref = orc.OracleBatch(n, P, 20, 10, seeds=seeds)
+print("chained:", eng.rollout_is_chained(1), eng.rollout_is_chained(8))
 c1, _ = eng.rollout_random(64, 1)
 c2, _ = eng.rollout_random(4, 8, first_step=64)
 _, want = ref.rollout_random(96, threads=min(32, len(os.sched_getaffinity(0))))
