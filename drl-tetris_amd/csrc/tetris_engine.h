@@ -55,6 +55,7 @@ TE_HD void st_stream(uint32_t* p, uint32_t v) { *p = v; }
 // clock at phase boundaries into a device buffer.  Product builds compile TE_STAMP to nothing.
 #if defined(TE_PHASE_TRACE) && defined(__HIPCC__)
 __device__ unsigned long long d_trace[2048 * 16];
+__device__ unsigned long long d_chain_trace[8 * 1024 * 8];
 #endif
 #if defined(TE_PHASE_TRACE) && defined(__HIP_DEVICE_COMPILE__)
 __device__ __forceinline__ void te_stamp(int k, bool realtime = false) {
@@ -67,9 +68,30 @@ __device__ __forceinline__ void te_stamp(int k, bool realtime = false) {
 }
 #define TE_STAMP(k) te_stamp(k)
 #define TE_STAMP_RT(k) te_stamp(k, true)
+// chained launches (k_chain): 100 MHz real-time clock (comparable across CUs and launches), stamps of the last 8 epochs kept
+__device__ __forceinline__ void te_stamp_chain(uint32_t epoch, int k) {
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned long long t = __builtin_amdgcn_s_memrealtime();
+    if ((threadIdx.x & 63) == 0 && blockIdx.x < 1024) d_chain_trace[(((size_t)(epoch & 7u) * 1024) + blockIdx.x) * 8 + k] = t;
+    __builtin_amdgcn_sched_barrier(0);
+}
+// slot 7: where the wave runs — HW_ID (wave[3:0] simd[5:4] cu[11:8] sh[12] se[15:13]) | XCC_ID << 32
+__device__ __forceinline__ void te_stamp_place(uint32_t epoch) {
+    uint32_t hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    if ((threadIdx.x & 63) == 0 && blockIdx.x < 1024)
+        d_chain_trace[(((size_t)(epoch & 7u) * 1024) + blockIdx.x) * 8 + 7] = ((unsigned long long)xcc << 32) | hw;
+}
+#define TE_STAMP_CHAIN(e, k) te_stamp_chain(e, k)
+#define TE_STAMP_PLACE(e) te_stamp_place(e)
 #else
 #define TE_STAMP(k) do {} while (0)
 #define TE_STAMP_RT(k) do {} while (0)
+#endif
+#if !defined(TE_STAMP_CHAIN)
+#define TE_STAMP_PLACE(e) do {} while (0)
+#define TE_STAMP_CHAIN(e, k) do {} while (0)
 #endif
 
 // Test-only path counters (tests/cpu_harness defines TE_PATH_COUNTERS): how often the rare branches of the key interpreter

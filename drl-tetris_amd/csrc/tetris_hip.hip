@@ -12,6 +12,7 @@
 
 #include <mutex>
 #include <new>
+#include <chrono>
 #include <string>
 #include <vector>
 
@@ -65,6 +66,10 @@ __global__ __launch_bounds__(256) void k_game(KArgs a) {
 #define TE_CHAIN_LANES 64          // games per wave of k_chain (experiment knob: 32 / 16 = emptier waves, more of them per SIMD)
 #endif
 constexpr int CHAIN_LANES = TE_CHAIN_LANES;
+#ifndef TE_CHAIN_STREAMS
+#define TE_CHAIN_STREAMS 2         // streams the chained launches rotate over = launches in flight (experiment knob)
+#endif
+constexpr int CHAIN_STREAMS = TE_CHAIN_STREAMS;
 template <int P>
 __global__ __launch_bounds__(64) void k_chain(KArgs a) {
     __shared__ __attribute__((aligned(16))) uint32_t s_shapes[SHAPE_WORDS];
@@ -74,19 +79,37 @@ __global__ __launch_bounds__(64) void k_chain(KArgs a) {
     LaneCounters cnt = {0, 0, 0, 0};
     const uint32_t shape_word = d_shape_table.s[lane];
     Game<P> g;
-    // the policy draw of this step depends on kernel arguments only: its 40 dependent multiplies run while the wave waits
+    // the policy draw of this step depends on kernel arguments only: its 40 dependent multiplies run while the wave waits.
+    // (Issuing the first poll of the epoch word BEFORE the draw — most waves find their predecessor done at that poll — measured
+    // +0.06 us per launch, GPU-paced: profiles/r02/chain_ab_gpu_paced.txt.)
+    TE_STAMP_CHAIN(a.epoch, 0); TE_STAMP_PLACE(a.epoch);
     if (active) policy_draw(a, (uint32_t)i, a.first_step, g.draw0, g.draw1);
     const uint32_t d0 = g.draw0, d1 = g.draw1;
+    TE_STAMP_CHAIN(a.epoch, 1);
     if (!chain_wait(a, (uint32_t)wave)) {
         if (lane == 0) { ((volatile uint32_t*)a.status)[F_CHAIN] = 1u; st_agent(a.chain + wave, CHAIN_POISON); }
         return;
     }
+    TE_STAMP_CHAIN(a.epoch, 2);
     if (active) { load_game<P>(geo_of(a), (size_t)i, g, false, P > 1, true, MEM_AGENT, CHAIN_LANES == 64); g.draw0 = d0; g.draw1 = d1; }
+#if defined(TE_PHASE_TRACE)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // diagnostic: when have ALL state words arrived
+    TE_STAMP_CHAIN(a.epoch, 3);
+#endif
     s_shapes[lane] = shape_word;
     __builtin_amdgcn_wave_barrier();
     if (active) game_run<P, M_ROLLOUT, false, MEM_AGENT>(a, i, s_shapes, g, cnt);
+    TE_STAMP_CHAIN(a.epoch, 4);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every store (and counter atomic) of this wave has been acknowledged
+    TE_STAMP_CHAIN(a.epoch, 5);
     if (lane == 0) st_agent(a.chain + wave, a.epoch);
+    TE_STAMP_CHAIN(a.epoch, 6);
+}
+
+// Debug aid (TETRIS_PREQUEUE=1): keeps a stream busy for ~`loops` x 64 clock cycles so that the launches enqueued behind it are all
+// queued before the first one starts — the GPU-paced launch period without any host pacing.
+__global__ void k_blocker(int loops) {
+    for (int k = 0; k < loops; k++) __builtin_amdgcn_s_sleep(1);
 }
 
 // Sums the per-game cumulative rollout counters (G_STEPS, G_EPISODE, G_LINES, G_SENT): run once before and once
@@ -632,7 +655,7 @@ struct tetris_batch {
     uint32_t* d_shadow = nullptr;        // split mode, side 1
     hipStream_t own_stream = nullptr;
     // chained launches (k_chain): two extra streams, one epoch word per wave, the number of the last chained launch
-    hipStream_t chain_stream[2] = {nullptr, nullptr};
+    hipStream_t chain_stream[CHAIN_STREAMS] = {};
     hipEvent_t chain_ev[3] = {nullptr, nullptr, nullptr};
     uint32_t* d_chain = nullptr;
     uint32_t chain_epoch = 0;
@@ -708,7 +731,7 @@ static bool chain_fits(tetris_batch* b) {
         b->chain_capacity = per_cu > 1 ? (long long)(per_cu - 1) * cus : 0;
     }
     const long long waves = b->P == 1 ? ((long long)b->N + CHAIN_LANES - 1) / CHAIN_LANES : ((long long)b->N + 31) / 32;
-    return 2 * waves <= b->chain_capacity;
+    return CHAIN_STREAMS * waves <= b->chain_capacity;
 }
 
 // Looks at the flag words WITHOUT enqueuing or waiting for anything: answers a pending "extend the RNG tables" request
@@ -744,7 +767,11 @@ static int gate_launch(tetris_batch* b, int group = GATE_GROUP) {
         b->gate_count = 0;
     }
     b->gate_count++;
-    if (b->stream != b->chain_stream[0] && b->stream != b->chain_stream[1]) b->home_async = true;
+    {
+        bool on_chain = false;
+        for (hipStream_t st : b->chain_stream) on_chain |= b->stream == st;
+        if (!on_chain) b->home_async = true;
+    }
     return service_flags(b);
 }
 
@@ -766,7 +793,7 @@ static int finish_call(tetris_batch* b) {
         if (!b->busy) return TETRIS_OK;           // (an extension would have enqueued work)
     }
     if (b->chain_pending) {
-        for (int k = 0; k < 2; k++) HIP_TRY(drain_stream(b->chain_stream[k]));
+        for (int k = 0; k < CHAIN_STREAMS; k++) HIP_TRY(drain_stream(b->chain_stream[k]));
         b->chain_pending = false;
     }
     HIP_TRY(drain_stream(b->stream));
@@ -826,6 +853,9 @@ extern "C" int tetris_debug_trace(unsigned long long* out, int n_words) {
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(d_trace), (size_t)n_words * 8) != hipSuccess) return -1;
     static unsigned long long zero[2048 * 16];
     return hipMemcpyToSymbol(HIP_SYMBOL(d_trace), zero, sizeof zero) == hipSuccess ? 0 : -1;
+}
+extern "C" int tetris_debug_chain_trace(unsigned long long* out /*[8][1024][8]*/) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(d_chain_trace), sizeof(unsigned long long) * 8 * 1024 * 8) == hipSuccess ? 0 : -1;
 }
 #endif
 
@@ -915,7 +945,7 @@ static int create_impl(tetris_batch** out, int n_games, int n_players, int heigh
     b->own_stream = b->stream;
     CREATE_TRY(hipEventCreate(&b->ev0));
     CREATE_TRY(hipEventCreate(&b->ev1));
-    for (int k = 0; k < 2; k++) CREATE_TRY(hipStreamCreateWithFlags(&b->chain_stream[k], hipStreamNonBlocking));
+    for (int k = 0; k < CHAIN_STREAMS; k++) CREATE_TRY(hipStreamCreateWithFlags(&b->chain_stream[k], hipStreamNonBlocking));
     for (int k = 0; k < 3; k++) CREATE_TRY(hipEventCreateWithFlags(&b->chain_ev[k], hipEventDisableTiming));
     {
         const size_t chain_bytes = (((size_t)n_games + 15) / 16) * sizeof(uint32_t);       // (one word per wave; at least 16 games per wave)
@@ -1610,16 +1640,28 @@ int tetris_rollout_launch(tetris_batch* b, int launches, int steps_per_launch, u
         // both chain streams start behind the asynchronous work the batch's stream still holds (after a synchronous call it
         // is empty and nothing has to be ordered)
         HIP_TRY(hipEventRecord(b->chain_ev[2], home));
-        for (int k = 0; k < 2; k++) HIP_TRY(hipStreamWaitEvent(b->chain_stream[k], b->chain_ev[2], 0));
+        for (int k = 0; k < CHAIN_STREAMS; k++) HIP_TRY(hipStreamWaitEvent(b->chain_stream[k], b->chain_ev[2], 0));
+    }
+    static const bool prequeue = getenv("TETRIS_PREQUEUE") != nullptr;
+    if (chained && prequeue && launches <= 600) {
+        hipLaunchKernelGGL(k_blocker, dim3(1), dim3(64), 0, home, 200000);           // ~5 ms
+        HIP_TRY(hipEventRecord(b->chain_ev[2], home));
+        for (int k = 0; k < CHAIN_STREAMS; k++) HIP_TRY(hipStreamWaitEvent(b->chain_stream[k], b->chain_ev[2], 0));
+        group = 1 << 20;
     }
     HIP_TRY(hipEventRecord(b->ev0, chained ? b->chain_stream[0] : home));
     struct StreamGuard {                          // base_args / launch_game / gate_launch work on b->stream
         tetris_batch* b; hipStream_t home;
         ~StreamGuard() { b->stream = home; }
     } stream_guard{b, home};
+    static const bool timing = getenv("TETRIS_TIMING") != nullptr;         // debug aid: host-side cost of this loop on stderr
+    const auto t_begin = std::chrono::steady_clock::now();
+    double gate_s = 0.0;
     for (int l = 0; l < launches; l++) {
-        if (chained) { b->stream = b->chain_stream[l & 1]; b->chain_pending = true; }
+        if (chained) { b->stream = b->chain_stream[l % CHAIN_STREAMS]; b->chain_pending = true; }
+        const auto t_gate = std::chrono::steady_clock::now();
         if ((rc = gate_launch(b, group))) return rc;
+        if (timing) gate_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_gate).count();
         KArgs a = base_args(b, b->N, nullptr);
         a.ms = ms; a.steps = steps_per_launch; a.policy_seed = policy_seed;
         a.first_step = first_step + (uint64_t)l * (uint64_t)steps_per_launch;
@@ -1634,7 +1676,13 @@ int tetris_rollout_launch(tetris_batch* b, int launches, int steps_per_launch, u
     // the last launch ends after every wave of the launch before it has published its epoch: its stream carries the end event
     HIP_TRY(hipEventRecord(b->ev1, b->stream));
     b->stream = home;
+    const auto t_enq = std::chrono::steady_clock::now();
     if ((rc = finish_call(b))) return rc;         // drains both chain streams and the batch's own
+    if (timing) {
+        const double enq = std::chrono::duration<double>(t_enq - t_begin).count(), all = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+        fprintf(stderr, "[tetris timing] %d launches: host enqueue %.2f us/launch (of which gate + flags %.2f), until drained %.2f us/launch\n",
+                launches, enq * 1e6 / launches, gate_s * 1e6 / launches, all * 1e6 / launches);
+    }
     if (elapsed_ms) HIP_TRY(hipEventElapsedTime(elapsed_ms, b->ev0, b->ev1));
     return TETRIS_OK;
 }
