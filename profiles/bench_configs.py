@@ -86,6 +86,25 @@ for name, with_after, planar in (("rows", True, False), ("planar", True, True), 
         "GBps": nbytes / (us * 1e-6) / 1e9, "frac_of_8TBps": nbytes / (us * 1e-6) / 8e12}
 b.close()
 
+# the same kernel at four times C4's size: the launch + first-load prologue is amortised over 115 MB of output
+b = pkg.TetrisBatch(65536, 1, 20, 10, seeds=np.arange(65536))
+advance(b, 12)
+n = 65536
+valid, land, cleared = torch.zeros(n * 40, **dv), torch.zeros(n * 40, dtype=torch.int8, device="cuda"), torch.zeros(n * 40, **dv)
+after = torch.zeros(n * 400, dtype=torch.int32, device="cuda")
+torch.cuda.synchronize()
+for _ in range(5):
+    b.enumerate_drops_dev(n, ptr(valid), ptr(land), ptr(cleared), ptr(after), planar=True)
+b.timer_start()
+for _ in range(reps):
+    b.enumerate_drops_dev(n, ptr(valid), ptr(land), ptr(cleared), ptr(after), planar=True)
+us = b.timer_stop() * 1e3 / reps
+nbytes = n * 44 + n * 40 * 43
+out["C4x4_enumerate_drops_64k_device_planar"] = {"us_per_call": us, "afterstates_per_s": n * 40 / (us * 1e-6), "algorithmic_bytes": nbytes,
+                                                 "GBps": nbytes / (us * 1e-6) / 1e9, "frac_of_8TBps": nbytes / (us * 1e-6) / 8e12}
+b.close()
+del valid, land, cleared, after
+
 b = pkg.TetrisBatch(65536, 2, 20, 10, seeds=np.arange(65536))
 advance(b, 12)
 n = 65536

@@ -79,6 +79,19 @@ for rep in range(3):
     c = buf2.reshape(2048, 16)[:1024].astype(np.int64)
     print("  inside the step (last launch, shader clock / 2470 per us): " +
           "; ".join(f"{PH[a]} -> {PH[b_]}: {np.median((c[:, b_] - c[:, a]) / 2470.0):.2f}" for a, b_ in zip(PH_ORDER[:-1], PH_ORDER[1:])))
+    # the slowest waves of the last launch: which part of the step took long?
+    last = int(np.argmax(t[:, 0, 0]))
+    comp = t[last, :, 4] - t[last, :, 3]
+    worst = np.argsort(comp)[::-1][:8]
+    keys = [k for k in PH_ORDER if (c[:, k] != 0).all()]
+    print("  slowest waves of the last launch (state arrived -> stores issued, then the in-step phases in the order above; last column: tick done -> stores issued incl. reset):")
+    for w in list(worst) + [-1]:
+        if w < 0:
+            ph = " ".join(f"{np.median((c[:, b_] - c[:, a]) / 2470.0):4.2f}" for a, b_ in zip(keys[:-1], keys[1:]))
+            print(f"   median wave      {np.median(comp):4.2f} | {ph}")
+        else:
+            ph = " ".join(f"{(c[w, b_] - c[w, a]) / 2470.0:4.2f}" for a, b_ in zip(keys[:-1], keys[1:]))
+            print(f"   wave {w:4d} (xcd {xcc[last, w]} cu {cu[last, w]:2d} simd {simd[last, w]}) {comp[w]:4.2f} | {ph}")
     span = t[e, :, 0].max(axis=1) - t[e, :, 0].min(axis=1)
     print(f"  dispatch ramp (first to last wave entry of one launch): {np.median(span):.2f} us;  launch-to-launch first entry: {np.median(np.diff(t[:, :, 0].min(axis=1))):.2f} us")
 b.close()
