@@ -204,6 +204,18 @@ def main():
     res = shard.run(args.steps, S)                    # exactly K timed launches
     counters, wall, ev_ms = res["counters"], res["wall_s"], res["event_ms"]
     batch = shard
+    # after the timed region, single GPU, chained single-step launches only: the same launches GPU-paced (the library parks its
+    # streams behind a blocker kernel until all 512 launches are queued) — the period the GPU sustains when the host's launch
+    # cost (2.5-5 us per launch, it varies between processes and boxes and sets the pace where it exceeds the GPU's period)
+    # does not enter.  Reported beside the wall-clock figures, never as `value`.
+    gpu_paced_us = None
+    if world == 1 and S == 1 and shard.batch.rollout_is_chained(S) and os.environ.get("BENCH_LIB_PATH") is None:
+        os.environ["TETRIS_PREQUEUE"] = "1"
+        try:
+            shard.run(64, S)
+            gpu_paced_us = min(shard.run(512, S)["event_ms"] for _ in range(2)) * 1e3 / 512
+        finally:
+            del os.environ["TETRIS_PREQUEUE"]
     # chained launches (include/tetris_hip.h: tetris_set_chained): on by default where two launches fit on the device together —
     # 64k single-player boards do, 64k two-player boards (k_duo needs 220 VGPRs) do not
     chained = shard.batch.rollout_is_chained(S)
@@ -231,6 +243,10 @@ def main():
             achieved = algo_bytes / (launch_us * 1e-6) / 1e9
             roofline.update({"achieved": achieved, "frac": achieved / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": algo_bytes,
                              "frac_kernel": (algo_bytes / (launch_us_events * 1e-6) / 1e9 / HBM_PEAK_GBS) if launch_us_events else None})
+            if gpu_paced_us:
+                roofline.update({"launch_us_gpu_paced": gpu_paced_us, "frac_gpu_paced": algo_bytes / (gpu_paced_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                 "gpu_paced_note": "extra run AFTER the timed region: 512 launches queued behind a blocker kernel before the first starts "
+                                                   "(HIP events); `value`, `launch_us` and `frac` above are the host-paced wall clock of the K timed launches"})
             # HBM traffic cannot be measured inside this process: it comes from separate rocprofv3 --pmc passes over this same
             # command (profiles/pmc_passes.sh), corrected as MI355X_MICROARCH.md prescribes; the file is named next to the number
             pmc = os.path.join(ROOT, "profiles", "r02", f"pmc_p{P}_s{S}.json")

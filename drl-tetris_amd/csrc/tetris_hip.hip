@@ -1642,7 +1642,10 @@ int tetris_rollout_launch(tetris_batch* b, int launches, int steps_per_launch, u
         HIP_TRY(hipEventRecord(b->chain_ev[2], home));
         for (int k = 0; k < CHAIN_STREAMS; k++) HIP_TRY(hipStreamWaitEvent(b->chain_stream[k], b->chain_ev[2], 0));
     }
-    static const bool prequeue = getenv("TETRIS_PREQUEUE") != nullptr;
+    // Measurement aid (TETRIS_PREQUEUE=1, read per call; bench.py's `launch_us_gpu_paced`): the chain streams are parked behind a
+    // ~5 ms blocker kernel while the host enqueues, so every launch of the call is queued before the first one starts and the
+    // host's launch cost does not enter the period.  No run-ahead gate in such a call (it would wait for the blocker): <= 600 launches.
+    const bool prequeue = getenv("TETRIS_PREQUEUE") != nullptr;
     if (chained && prequeue && launches <= 600) {
         hipLaunchKernelGGL(k_blocker, dim3(1), dim3(64), 0, home, 200000);           // ~5 ms
         HIP_TRY(hipEventRecord(b->chain_ev[2], home));
