@@ -1576,6 +1576,7 @@ int tetris_rollout_is_chained(tetris_batch* b, int steps_per_launch) {
 
 int tetris_rollout_launch(tetris_batch* b, int launches, int steps_per_launch, uint32_t policy_seed, uint64_t first_step,
                           int ms, float* elapsed_ms) {
+    const auto t_entry = std::chrono::steady_clock::now();
     int rc = check_batch(b);
     if (rc) return rc;
     if (launches < 1 || steps_per_launch < 0) return fail(TETRIS_E_ARG, "launches must be >= 1, steps_per_launch >= 0");
@@ -1681,12 +1682,15 @@ int tetris_rollout_launch(tetris_batch* b, int launches, int steps_per_launch, u
     b->stream = home;
     const auto t_enq = std::chrono::steady_clock::now();
     if ((rc = finish_call(b))) return rc;         // drains both chain streams and the batch's own
+    if (elapsed_ms) HIP_TRY(hipEventElapsedTime(elapsed_ms, b->ev0, b->ev1));
     if (timing) {
         const double enq = std::chrono::duration<double>(t_enq - t_begin).count(), all = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
-        fprintf(stderr, "[tetris timing] %d launches: host enqueue %.2f us/launch (of which gate + flags %.2f), until drained %.2f us/launch\n",
-                launches, enq * 1e6 / launches, gate_s * 1e6 / launches, all * 1e6 / launches);
+        fprintf(stderr, "[tetris timing] %d launches: host enqueue %.2f us/launch (of which gate + flags %.2f), until drained %.2f us/launch; "
+                "call entry -> first enqueue %.1f us, whole call %.1f us, between the events %.1f us\n",
+                launches, enq * 1e6 / launches, gate_s * 1e6 / launches, all * 1e6 / launches,
+                std::chrono::duration<double>(t_begin - t_entry).count() * 1e6, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_entry).count() * 1e6,
+                elapsed_ms ? *elapsed_ms * 1e3 : 0.0);
     }
-    if (elapsed_ms) HIP_TRY(hipEventElapsedTime(elapsed_ms, b->ev0, b->ev1));
     return TETRIS_OK;
 }
 
