@@ -183,8 +183,9 @@ def main():
         return bench_split(args, sharded, dist, rank, world, local_rank)
     N, P, S = args.games, args.players, args.steps_per_launch
     # rank r owns global games [r*N, (r+1)*N): distinct policy stream and seed schedule per rank, no collective
-    # on the data path; ShardedRollout brackets the timed launches with barrier + synchronize on both sides and
-    # reduces time (MAX) and counters (SUM) over the ranks.
+    # on the data path; ShardedRollout brackets the timed launches with barrier + synchronize on both sides (each rank's clock
+    # stops when ITS launches have drained, before the closing barrier: that barrier is no part of the K steps and over RCCL it
+    # costs as much as a short rollout) and reduces time (MAX) and counters (SUM) over the ranks.
     shard = sharded.ShardedRollout(N, P, args.height, 10, rank=rank, world=world, device=local_rank, dist=dist,
                                    lib_path=os.environ.get("BENCH_LIB_PATH"))   # (set only to rehearse the N>1 launch without GPUs)
     precondition_launches = 0

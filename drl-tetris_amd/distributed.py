@@ -43,18 +43,29 @@ class ShardedRollout:
                 torch.cuda.synchronize()
         self.batch.sync()
 
+    def _drain(self):
+        if self.dist is not None:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+        self.batch.sync()
+
     def run(self, launches, steps_per_launch=1, timed=True):
         """Advances every game of every rank by launches * steps_per_launch env-steps.
         -> dict(counters = sum over ranks [env_steps, episodes, lines, sent], wall_s and event_ms = max over ranks).
-        Only the step-kernel launches lie inside the clocked region (barrier + synchronize on both sides of it): the
+        Only the step-kernel launches lie inside the clocked region (barrier + synchronize on both sides of it; the closing
+        barrier itself is not clocked, see below): the
         counters are per-game words kept by the kernels themselves (env-steps are counted on the device) and are summed by a
         separate kernel before and after, outside the region."""
         before = self.batch.rollout_totals()
-        self._sync()
+        self._sync()                                   # opening bracket: barrier over the ranks + synchronize
         t0 = time.perf_counter()
         ev_ms = self.batch.rollout_launch(launches, steps_per_launch, first_step=self.next_step)
-        self._sync()
+        self._drain()                                  # this rank's launches have finished (the call above already waited for them)
         wall = time.perf_counter() - t0
+        self._sync()                                   # closing bracket; the clock stops BEFORE it: a barrier over RCCL costs tens of
+                                                       # microseconds, as much as a short rollout, and is no part of the K steps — the
+                                                       # reported time is the MAX over ranks of each rank's own start-to-drained time
         counters = (self.batch.rollout_totals() - before).astype(np.int64)
         self.next_step += launches * steps_per_launch
         if self.dist is not None:
