@@ -64,6 +64,8 @@ _SIGNATURES = {
     "tetris_step_rt": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "tetris_step_rt_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "tetris_step_rt_dev_ex": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "tetris_step_rt_observe_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "tetris_reset_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "tetris_observe_records": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "tetris_snapshot": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
@@ -248,6 +250,12 @@ class TetrisBatch:
         """tetris_step_rt_dev_ex: every argument is a raw DEVICE address (int / c_void_p) or None; only enqueues.
         auto_reset: finished games are reset inside the launch with the next seed of the built-in schedule."""
         self._check(self.lib.tetris_step_rt_dev_ex(self._h, rot, trans, player, int(ms), done, lines, dead, 1 if auto_reset else 0))
+
+    def step_rt_observe_dev(self, rot, trans, player, done, lines, dead, next_player, visual, vector, piece, ms=400, auto_reset=False):
+        """tetris_step_rt_observe_dev: the step of step_rt_dev and the packed observation of the stepped state (perspective of
+        next_player) in one launch; every argument is a raw DEVICE address or None; only enqueues."""
+        self._check(self.lib.tetris_step_rt_observe_dev(self._h, rot, trans, player, int(ms), done, lines, dead, 1 if auto_reset else 0,
+                                                        next_player, visual, vector, piece))
 
     def reset_dev(self, mask=None, seeds=None):
         """tetris_reset_dev: device mask [N] (None = all games), device seeds int16 [N] (None = built-in schedule); only enqueues."""

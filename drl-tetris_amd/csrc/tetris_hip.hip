@@ -129,6 +129,90 @@ __global__ __launch_bounds__(256) void k_totals(Geo geo, unsigned long long* out
     }
 }
 
+// ---- step + observation in one launch (tetris_step_rt_observe_dev) ------------------------------------------------------------
+// One agent-loop iteration in ONE launch (worker.py:91-118: perform_action, then get_state + unpack for the next decision): the
+// (r, t) step and, straight from the registers the step leaves behind, the packed observation k_observe_packed would rebuild
+// from the stored state — no second launch, no second read of the state.  A wave's byte planes go through an LDS tile and leave
+// as contiguous runs of 16-byte stores.  Even heights only (H * 10 cells = whole words per board).
+// one board -> its row of the tile, its 12 vector bytes and its piece byte (slot sl, game i): as k_observe_packed
+// (a macro, not a function: as an inlined function with the board passed by reference, by value or as seventeen scalars, the
+// compiler left the step's column array in scratch memory — 128 B per lane and +1.5 us per launch)
+#define TE_OBS_BUILD(a, row, sl, i, COL, qx, qy, qnext, qkind, qinc, qcombo, qrem)                                              \
+    do {                                                                                                                        \
+        uint32_t col_[NCOL];                                                                                                    \
+        TE_UNROLL                                                                                                               \
+        for (int c = 0; c < NCOL; c++) col_[c] = COL(c);                                                                        \
+        for (int yp = 0; yp < (a).H / 2; yp++) {                                                                                \
+            uint32_t lo[NCOL], hi[NCOL]; /* cells of rows 2 yp and 2 yp + 1 */                                                  \
+            TE_UNROLL                                                                                                           \
+            for (int c = 0; c < NCOL; c++) { lo[c] = col_[c] & 1u; hi[c] = (col_[c] >> 1) & 1u; col_[c] >>= 2; }                \
+            (row)[5 * yp + 0] = lo[0] | (lo[1] << 8) | (lo[2] << 16) | (lo[3] << 24);                                           \
+            (row)[5 * yp + 1] = lo[4] | (lo[5] << 8) | (lo[6] << 16) | (lo[7] << 24);                                           \
+            (row)[5 * yp + 2] = lo[8] | (lo[9] << 8) | (hi[0] << 16) | (hi[1] << 24);                                           \
+            (row)[5 * yp + 3] = hi[2] | (hi[3] << 8) | (hi[4] << 16) | (hi[5] << 24);                                           \
+            (row)[5 * yp + 4] = hi[6] | (hi[7] << 8) | (hi[8] << 16) | (hi[9] << 24);                                           \
+        }                                                                                                                       \
+        /* state_processors.py:23-54 vector: x, y, incoming, combo time, combo count, one-hot next piece */                     \
+        const uint32_t x_ = (uint32_t)(qx) & 0xFFu, y_ = (uint32_t)(qy) & 31u, next_ = (uint32_t)(qnext) & 7u;                  \
+        uint32_t t_ = (((uint32_t)(qrem) & 0xFFFFu) + 50u) & 0xFFFFu; /* uint16 + 50 wraps like numpy (state_processors.py:38) */ \
+        if (t_ > 25000u) t_ = 25000u;                                                                                           \
+        uint32_t* v_ = (uint32_t*)((a).obs_vector + ((size_t)(sl) * (a).n + (i)) * 12);                                         \
+        const uint64_t hot_ = next_ < 7u ? (1ull << (8 * next_)) : 0ull; /* bytes 5..11 */                                      \
+        v_[0] = x_ | (y_ << 8) | (((uint32_t)(qinc) & 255u) << 16) | ((t_ / 100u) << 24);                                       \
+        v_[1] = ((uint32_t)(qcombo) & 255u) | ((uint32_t)(hot_ & 0xFFFFFFu) << 8);                                              \
+        v_[2] = (uint32_t)(hot_ >> 24);                                                                                         \
+        (a).obs_piece[(size_t)(sl) * (a).n + (i)] = (uint8_t)((uint32_t)(qkind) & 7u);                                          \
+    } while (0)
+// the same as a function of scalars — the form that stays in registers inside k_duo (there the macro cost 784 B of scratch per lane)
+__device__ __forceinline__ void obs_build(const KArgs& a, uint32_t* row, int sl, int i, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t c4,
+                                          uint32_t c5, uint32_t c6, uint32_t c7, uint32_t c8, uint32_t c9, int qx, int qy, int qnext, int qkind,
+                                          int inc_count, int combo_count, uint32_t combo_remaining) {
+    const uint32_t cols[NCOL] = {c0, c1, c2, c3, c4, c5, c6, c7, c8, c9};
+#define TE_OBS_COL(c) cols[c]
+    TE_OBS_BUILD(a, row, sl, i, TE_OBS_COL, qx, qy, qnext, qkind, inc_count, combo_count, combo_remaining);
+#undef TE_OBS_COL
+}
+// `nb` consecutive tile rows (boards first .. first + nb of slot sl) -> visual, by the 64 lanes of one wave.  The tile is NOT padded
+// (row pitch = nw words), so it is the output image itself: one 16-byte LDS read per 16-byte store, no index arithmetic.  (The rows
+// of a wave's lanes then start 50 / 55 / ... words apart: two lanes per LDS bank at most while the rows are written.)
+__device__ __forceinline__ void obs_stream(const KArgs& a, const uint32_t* rows, int sl, int first, int nb, int lane) {
+    const int nw = a.H * NCOL / 4;
+    uint32_t* dst = (uint32_t*)(a.obs_visual + ((size_t)sl * a.n + first) * (size_t)(a.H * NCOL));
+    const uint32_t words = (uint32_t)nb * (uint32_t)nw;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    if (((((uintptr_t)dst) | ((uintptr_t)rows)) & 15u) == 0) {
+        const uint32_t whole = words & ~3u;
+        for (uint32_t k = 4u * (uint32_t)lane; k < whole; k += 4u * 64u)
+            __builtin_nontemporal_store(*reinterpret_cast<const u32x4*>(rows + k), reinterpret_cast<u32x4*>(dst + k));
+        if ((uint32_t)lane < words - whole) dst[whole + lane] = rows[whole + lane];
+    } else
+        for (uint32_t k = (uint32_t)lane; k < words; k += 64u) dst[k] = rows[k];
+}
+
+// lane = game (k_step_observe): slot 0 = the deciding player's board, slot 1 = the opponent's, one slot after the other
+template <int P>
+__device__ __forceinline__ void observe_emit(const KArgs& a, const Game<P>& g, int first, int lane, bool active, uint32_t* tile) {
+    const int pitch = a.H * NCOL / 4, i = first + lane;
+    const int nb = (a.n - first < 64) ? a.n - first : 64;
+    const int me = active ? safe_player(a.next_player, i, P) : 0;
+    TE_UNROLL
+    for (int sl = 0; sl < P; sl++) {
+        if (active) {
+            const bool sel = P > 1 && (sl == 0 ? me == 1 : me == 0);      // field-wise select of the second player's board
+            const Player& q0 = g.pl[0];
+            const Player& q1 = g.pl[P - 1];
+            uint32_t* row = tile + (size_t)lane * pitch;
+#define TE_OBS_COL(c) (sel ? q1.col[c] : q0.col[c])
+            TE_OBS_BUILD(a, row, sl, i, TE_OBS_COL, sel ? q1.x : q0.x, sel ? q1.y : q0.y, sel ? q1.next : q0.next, sel ? q1.kind : q0.kind,
+                         sel ? q1.inc_count : q0.inc_count, sel ? q1.combo_count : q0.combo_count, sel ? q1.combo_remaining : q0.combo_remaining);
+#undef TE_OBS_COL
+        }
+        __syncthreads();
+        obs_stream(a, tile, sl, first, nb, lane);
+        __syncthreads();
+    }
+}
+
 // "Duo" mapping for two-player games (BASELINE config 3): the two players of a game sit in lanes l and l ^ 32 of ONE wave,
 // so 64k games are 2 waves per SIMD instead of 1 and the second player's clear/spawn, timers and state traffic overlap with
 // the first's.  The in-step order dependence between the players is the split-mode stage protocol (tetris_engine.h) with
@@ -136,9 +220,12 @@ __global__ __launch_bounds__(256) void k_totals(Geo geo, unsigned long long* out
 // backup for the rollback when player 0 died), B0 / B1 = delayCheck of player 0, then player 1, C = winner logic.
 // CHAIN (rollout only, 64-thread workgroups): chained launches as in k_chain — a wave's 32 games wait for the epoch word the same
 // wave of the previous launch published, and all state traffic is agent-scope.
-template <int MODE, bool CHAIN = false>
+// OBS (tetris_step_rt_observe_dev): after the step every lane turns its own board into the packed observation — slot 0 if its
+// player is the one the game's next decision is for, slot 1 otherwise; rows 0..31 / 32..63 of the wave's LDS tile.
+template <int MODE, bool CHAIN = false, bool OBS = false>
 __global__ __launch_bounds__(256) void k_duo(KArgs a) {
     __shared__ __attribute__((aligned(16))) uint32_t s_shapes_all[4][SHAPE_WORDS];      // per-wave copy, no block barrier (see k_game)
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_duo_tile[];               // OBS: 4 waves x 64 rows x nw words
     uint32_t* s_shapes = s_shapes_all[threadIdx.x >> 6];
     const uint32_t shape_word = d_shape_table.s[threadIdx.x & 63];
     const int lane = threadIdx.x & 63, side = lane >> 5;
@@ -256,6 +343,21 @@ __global__ __launch_bounds__(256) void k_duo(KArgs a) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every store (and counter atomic) of this wave has been acknowledged
         if (lane == 0) st_agent(a.chain + wave, a.epoch);
     }
+    if (OBS) {
+        const int pitch = a.H * NCOL / 4, first = wave * 32;
+        uint32_t* tile = s_duo_tile + ((size_t)(threadIdx.x >> 6) * 64 * pitch + 3) / 4 * 4;       // (16-byte aligned per wave)
+        if (active) {
+            const int sl = side == safe_player(a.next_player, gi, 2) ? 0 : 1;
+            obs_build(a, tile + (size_t)(sl * 32 + (lane & 31)) * pitch, sl, gi, q.col[0], q.col[1], q.col[2], q.col[3], q.col[4], q.col[5], q.col[6],
+                      q.col[7], q.col[8], q.col[9], q.x, q.y, q.next, q.kind, q.inc_count, q.combo_count, q.combo_remaining);
+        }
+        __syncthreads();
+        const int nb = (a.n - first < 32) ? a.n - first : 32;
+        if (nb > 0) {
+            obs_stream(a, tile, 0, first, nb, lane);
+            obs_stream(a, tile + (size_t)32 * pitch, 1, first, nb, lane);
+        }
+    }
 }
 
 template <int STAGE, bool TINT>
@@ -333,14 +435,14 @@ __global__ __launch_bounds__(256) void k_observe_packed_bytes(Geo geo, int n, co
 
 // Even heights (H * 10 cells = a whole number of words per board, the usual 20 / 22 rows): the byte planes are built as
 // words in registers — two rows = 20 cells = 5 words per loop trip, columns indexed statically — and go to LDS as dwords
-// with a row stride of nw + 1 words (odd: conflict-free), instead of 200 byte writes per lane; the workgroup's tile then
-// leaves as coalesced dword stores.  The 12 vector bytes of a board leave as 3 dwords.
+// instead of 200 byte writes per lane; the workgroup's tile then leaves as coalesced 16-byte stores.  The 12 vector bytes of a
+// board leave as 3 dwords.
 template <int P, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_observe_packed(Geo geo, int n, const int32_t* idx,
                                                           const uint8_t* player, int H, uint8_t* visual, uint8_t* vector,
-                                                          uint8_t* piece, uint32_t inv_nw) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t s_words[];      // BLOCK * (nw + 1) words
-    const int nw = H * NCOL / 4, pitch = nw + 1;
+                                                          uint8_t* piece) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_words[];      // BLOCK * nw words: the workgroup's slice of `visual` itself
+    const int nw = H * NCOL / 4;
     const int i = blockIdx.x * BLOCK + threadIdx.x;
     const int first = blockIdx.x * BLOCK;
     const int nb = (n - first < BLOCK) ? n - first : BLOCK;
@@ -354,7 +456,7 @@ __global__ __launch_bounds__(BLOCK) void k_observe_packed(Geo geo, int n, const 
             uint32_t col[NCOL];
             for (int c = 0; c < NCOL; c++) col[c] = word_at(br, W_COL0 + c);
             const uint32_t w = word_at(br, W_PIECE), m = word_at(br, W_MISC), dc = word_at(br, W_DROPCOMBO);
-            uint32_t* row = s_words + (size_t)threadIdx.x * pitch;
+            uint32_t* row = s_words + (size_t)threadIdx.x * nw;
             for (int yp = 0; yp < H / 2; yp++) {
                 uint32_t lo[NCOL], hi[NCOL];                 // cells of rows 2 yp and 2 yp + 1
                 for (int c = 0; c < NCOL; c++) { lo[c] = col[c] & 1u; hi[c] = (col[c] >> 1) & 1u; col[c] >>= 2; }
@@ -376,25 +478,18 @@ __global__ __launch_bounds__(BLOCK) void k_observe_packed(Geo geo, int n, const 
             piece[(size_t)sl * n + i] = (uint8_t)(w & 7u);
         }
         __syncthreads();
+        // the tile is not padded (rows nw words apart: at most two lanes per LDS bank while it is written), so it IS the output
+        // image: one 16-byte LDS read per 16-byte streaming store, no index arithmetic
         uint32_t* dst = (uint32_t*)(visual + ((size_t)sl * n + first) * (size_t)(H * NCOL));
         const uint32_t words = (uint32_t)nb * (uint32_t)nw;
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
         if ((((uintptr_t)dst) & 15u) == 0) {
-            // the tile leaves as 16-byte streaming stores (a quarter of the store instructions); the four words of a store may
-            // straddle a board's row in the padded LDS tile, so each is fetched by its own index
-            for (uint32_t g = 4u * threadIdx.x; g < words; g += 4u * BLOCK) {
-                u32x4 v;
-                v.x = s_words[g + __umulhi(g, inv_nw)];      // g / nw (exact: g < 2^16, inv_nw = ceil(2^32 / nw))
-                if (g + 3u < words) {
-                    v.y = s_words[g + 1u + __umulhi(g + 1u, inv_nw)];
-                    v.z = s_words[g + 2u + __umulhi(g + 2u, inv_nw)];
-                    v.w = s_words[g + 3u + __umulhi(g + 3u, inv_nw)];
-                    __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(dst + g));
-                } else
-                    for (uint32_t k = g; k < words; k++) dst[k] = s_words[k + __umulhi(k, inv_nw)];
-            }
+            const uint32_t whole = words & ~3u;
+            for (uint32_t g = 4u * threadIdx.x; g < whole; g += 4u * BLOCK)
+                __builtin_nontemporal_store(*reinterpret_cast<const u32x4*>(s_words + g), reinterpret_cast<u32x4*>(dst + g));
+            if (threadIdx.x < words - whole) dst[whole + threadIdx.x] = s_words[whole + threadIdx.x];
         } else
-            for (uint32_t g = threadIdx.x; g < words; g += BLOCK) dst[g] = s_words[g + __umulhi(g, inv_nw)];
+            for (uint32_t g = threadIdx.x; g < words; g += BLOCK) dst[g] = s_words[g];
     }
 }
 
@@ -483,6 +578,23 @@ __global__ __launch_bounds__(ENUM_BLOCK) void k_enumerate(Geo geo, int n, const 
                 for (int c = 0; c < NCOL; c++) after[t * NCOL + c] = enum_after_col(board[c], pl, c);      // 40 contiguous bytes per lane: left to the L2 to merge
         }
     }
+}
+
+template <int P, int MODE>
+__global__ __launch_bounds__(64) void k_step_observe(KArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_step_obs[];     // [SHAPE_WORDS] shape table, then the 64 x nw tile
+    uint32_t* s_shapes = s_step_obs;
+    uint32_t* tile = s_step_obs + SHAPE_WORDS;
+    const int lane = threadIdx.x, first = blockIdx.x * 64, i = first + lane;
+    const bool active = i < a.n;
+    LaneCounters cnt = {0, 0, 0, 0};
+    const uint32_t shape_word = d_shape_table.s[lane];
+    Game<P> g;
+    if (active) game_load<P, MODE, false>(a, i, g);
+    s_shapes[lane] = shape_word;
+    __builtin_amdgcn_wave_barrier();
+    if (active) game_run<P, MODE, false>(a, i, s_shapes, g, cnt);
+    observe_emit<P>(a, g, first, lane, active, tile);
 }
 
 template <int P>
@@ -1223,6 +1335,50 @@ int tetris_step_rt_dev_ex(tetris_batch* b, const uint8_t* d_rot, const uint8_t* 
     return (flags & TETRIS_STEP_AUTO_RESET) ? launch_game<M_STEP_RT_AUTO>(b, a) : launch_game<M_STEP_RT>(b, a);
 }
 
+int tetris_step_rt_observe_dev(tetris_batch* b, const uint8_t* d_rot, const uint8_t* d_trans, const uint8_t* d_player, int ms,
+                               uint8_t* d_done, uint8_t* d_lines, uint8_t* d_dead, int flags, const uint8_t* d_next_player,
+                               uint8_t* d_visual, uint8_t* d_vector, uint8_t* d_piece) {
+    int rc = check_batch(b);
+    if (rc) return rc;
+    if (!d_rot || !d_trans) return fail(TETRIS_E_ARG, "rot/trans are NULL");
+    if (!d_visual || !d_vector || !d_piece) return fail(TETRIS_E_ARG, "visual/vector/piece are NULL");
+    if (flags & ~TETRIS_STEP_AUTO_RESET) return fail(TETRIS_E_ARG, "unknown flag");
+    if (b->split) return fail(TETRIS_E_ARG, "tetris_step_rt_observe_dev is not available on split batches");
+    const bool fused = !b->tint && b->H % 2 == 0 && ((uintptr_t)d_visual & 3u) == 0 && ((uintptr_t)d_vector & 3u) == 0;
+    if (!fused) {             // colour batches, odd heights, unaligned outputs: the same two kernels back to back
+        if ((rc = tetris_step_rt_dev_ex(b, d_rot, d_trans, d_player, ms, d_done, d_lines, d_dead, flags))) return rc;
+        return tetris_observe_packed_dev(b, nullptr, b->N, d_next_player, d_visual, d_vector, d_piece);
+    }
+    if ((rc = gate_launch(b))) return rc;
+    KArgs a = base_args(b, b->N, nullptr);
+    a.rot = d_rot; a.trans = d_trans; a.player = d_player; a.ms = ms;
+    a.done = d_done; a.lines = d_lines; a.dead = d_dead;
+    a.next_player = d_next_player; a.obs_visual = d_visual; a.obs_vector = d_vector; a.obs_piece = d_piece;
+    const int nw = b->H * NCOL / 4;
+        const size_t lds = ((size_t)SHAPE_WORDS + (size_t)64 * nw) * 4;
+    const dim3 grid((unsigned)((b->N + 63) / 64)), block(64);
+    const bool autoreset = (flags & TETRIS_STEP_AUTO_RESET) != 0;
+    if (b->P == 1) {
+        if (autoreset) hipLaunchKernelGGL((k_step_observe<1, M_STEP_RT_AUTO>), grid, block, lds, b->stream, a);
+        else hipLaunchKernelGGL((k_step_observe<1, M_STEP_RT>), grid, block, lds, b->stream, a);
+    } else if (b->use_duo) {
+        // two players: one player per lane (k_duo) — every lane builds the one board it holds
+        const size_t lds2 = ((size_t)4 * 64 * nw + 16) * 4;
+        if (lds2 > 48 * 1024) {
+            const void* fn = autoreset ? (const void*)k_duo<M_STEP_RT_AUTO, false, true> : (const void*)k_duo<M_STEP_RT, false, true>;
+            HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+        }
+        const dim3 grid2((unsigned)((b->N + 127) / 128)), block2(256);
+        if (autoreset) hipLaunchKernelGGL((k_duo<M_STEP_RT_AUTO, false, true>), grid2, block2, lds2, b->stream, a);
+        else hipLaunchKernelGGL((k_duo<M_STEP_RT, false, true>), grid2, block2, lds2, b->stream, a);
+    } else {
+        if (autoreset) hipLaunchKernelGGL((k_step_observe<2, M_STEP_RT_AUTO>), grid, block, lds, b->stream, a);
+        else hipLaunchKernelGGL((k_step_observe<2, M_STEP_RT>), grid, block, lds, b->stream, a);
+    }
+    HIP_TRY(hipGetLastError());
+    return TETRIS_OK;
+}
+
 int tetris_step_rt_dev(tetris_batch* b, const uint8_t* d_rot, const uint8_t* d_trans, const uint8_t* d_player, int ms,
                        uint8_t* d_done, uint8_t* d_lines, uint8_t* d_dead) {
     return tetris_step_rt_dev_ex(b, d_rot, d_trans, d_player, ms, d_done, d_lines, d_dead, 0);
@@ -1307,15 +1463,14 @@ int tetris_observe_packed_dev(tetris_batch* b, const int32_t* d_idx, int n, cons
         // one wave per workgroup (<= 20 KB of LDS): several workgroups per CU overlap their load / build / store phases
         constexpr int OB = 64;
         const int nw = b->H * NCOL / 4;
-        const size_t lds = (size_t)OB * (nw + 1) * 4;
-        const uint32_t inv_nw = (uint32_t)(((1ull << 32) + (uint64_t)nw - 1) / (uint64_t)nw);
+        const size_t lds = (size_t)OB * nw * 4;
         dim3 ogrid((unsigned)((n + OB - 1) / OB), (unsigned)b->P), oblock(OB);
         if (b->P == 1)
             hipLaunchKernelGGL((k_observe_packed<1, OB>), ogrid, oblock, lds, b->stream, geo_of_batch(b), n, d_idx, d_player, b->H,
-                               d_visual, d_vector, d_piece, inv_nw);
+                               d_visual, d_vector, d_piece);
         else
             hipLaunchKernelGGL((k_observe_packed<2, OB>), ogrid, oblock, lds, b->stream, geo_of_batch(b), n, d_idx, d_player, b->H,
-                               d_visual, d_vector, d_piece, inv_nw);
+                               d_visual, d_vector, d_piece);
         HIP_TRY(hipGetLastError());
         return TETRIS_OK;
     }

@@ -48,6 +48,12 @@ struct KArgs {
     const uint32_t* xw[4];    // split mode: exchange words [n] each: my A, the opponent's A, player 0's B, player 1's B (separate buffers:
                               // the words a kernel wrote and the rows an all-gather delivered are read where they lie, no copies)
     uint32_t* xout;           // split mode: this stage's word per board [n]
+    // step + observation in one launch (k_step_observe): the packed observation of the stepped state, from the perspective of
+    // next_player[i] (NULL: player 0), in the layout of tetris_observe_packed_dev
+    const uint8_t* next_player;
+    uint8_t* obs_visual;      // [P][n][H][10]
+    uint8_t* obs_vector;      // [P][n][12]
+    uint8_t* obs_piece;       // [P][n]
 };
 
 enum Mode { M_INIT, M_RESET, M_MAKE, M_FINISH, M_STEP_KEYS, M_STEP_RT, M_ROLLOUT, M_SPLIT_INIT, M_SPLIT_RESET,

@@ -37,6 +37,16 @@ class TorchEnv:
                            self._ptr(self.dead), ms=ms, auto_reset=auto_reset)
         return self.done, self.lines, self.dead
 
+    def step_rt_observe(self, rot, trans, player=None, next_player=None, ms=400, auto_reset=False):
+        """One iteration of the agent loop in one launch: step_rt(...) and observe(next_player) of the stepped state.
+        -> (done, lines, dead, visual, vector, piece) device tensors (reused); bit-identical to the two calls."""
+        for t in (rot, trans) + tuple(x for x in (player, next_player) if x is not None):
+            assert t.dtype == self.torch.uint8 and t.is_cuda and t.is_contiguous() and t.numel() == self.b.n_games
+        self.b.step_rt_observe_dev(self._ptr(rot), self._ptr(trans), self._ptr(player), self._ptr(self.done), self._ptr(self.lines),
+                                   self._ptr(self.dead), self._ptr(next_player), self._ptr(self.visual), self._ptr(self.vector),
+                                   self._ptr(self.piece), ms=ms, auto_reset=auto_reset)
+        return self.done, self.lines, self.dead, self.visual, self.vector, self.piece
+
     def reset(self, mask=None, seeds=None):
         """Device-side reset: mask uint8 [n] device tensor (non-zero = reset; None = all), seeds int16 [n] device tensor
         (None = the built-in schedule).  Only enqueues."""

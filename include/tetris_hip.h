@@ -132,6 +132,17 @@ int tetris_step_rt_dev(tetris_batch *b, const uint8_t *d_rot, const uint8_t *d_t
 int tetris_step_rt_dev_ex(tetris_batch *b, const uint8_t *d_rot, const uint8_t *d_trans,
                           const uint8_t *d_player, int ms, uint8_t *d_done, uint8_t *d_lines,
                           uint8_t *d_dead, int flags);
+/* One iteration of the agent loop in ONE launch (drl_tetris/worker.py:91-118: perform_action, then get_state + the unpacker
+ * for the next decision): tetris_step_rt_dev_ex followed by tetris_observe_packed_dev(b, NULL, N, d_next_player, ...) of the
+ * stepped (and, with TETRIS_STEP_AUTO_RESET, reset) state — produced from the registers the step leaves behind instead of a
+ * second kernel that reads the state back.  d_next_player[N] = the player each game's next decision is for (NULL: player 0;
+ * out-of-range entries are clamped); d_visual [P][N][H][10], d_vector [P][N][12], d_piece [P][N] as tetris_observe_packed.
+ * Same outputs, bit for bit, as the two calls.  Colour batches, odd heights and outputs that are not 4-byte aligned run
+ * the two kernels back to back; not available on split batches.                                                        */
+int tetris_step_rt_observe_dev(tetris_batch *b, const uint8_t *d_rot, const uint8_t *d_trans,
+                               const uint8_t *d_player, int ms, uint8_t *d_done, uint8_t *d_lines,
+                               uint8_t *d_dead, int flags, const uint8_t *d_next_player,
+                               uint8_t *d_visual, uint8_t *d_vector, uint8_t *d_piece);
 /* replaces: reset() of the games selected by a DEVICE-side mask (d_mask[N], non-zero = reset; NULL = all games),
  * asynchronous.  d_seeds[N] int16 (device) or NULL = next seed of the built-in schedule (see above).              */
 int tetris_reset_dev(tetris_batch *b, const uint8_t *d_mask, const int16_t *d_seeds);

@@ -2,7 +2,8 @@
 """One secondary kernel, launched back to back with pre-built ctypes arguments (so the Python loop costs ~1 us per launch and
 does not bound what is measured); prints HIP-event time per launch.  Run it under `rocprofv3 --kernel-trace --stats` for the
 kernel's own duration (profiles/r02_kernels.sh):   python profiles/kernel_prof.py <case> [reps]
-cases: enum_rows enum_planar enum_noafter enum_noafter_planar observe step_auto_1p step_auto_2p"""
+cases: enum_rows enum_planar enum_noafter enum_noafter_planar observe step_auto_1p step_auto_2p step_obs_1p step_obs_2p loop_1p loop_2p
+(step_obs = tetris_step_rt_observe_dev, one launch; loop = tetris_step_rt_dev_ex + tetris_observe_packed_dev, two launches: the same work)"""
 import ctypes as C
 import json
 import os
@@ -53,6 +54,19 @@ else:
     fn = b.lib.tetris_step_rt_dev_ex
     args = (b._h, ptr(rot), ptr(trans), ptr(who), 400, ptr(done), ptr(lines), ptr(dead), 1)       # TETRIS_STEP_AUTO_RESET
     nbytes = (389 if P == 1 else 774) * n
+    if case.startswith("step_obs") or case.startswith("loop"):
+        visual, vector, piece = torch.zeros(P * n * 200, **dv), torch.zeros(P * n * 12, **dv), torch.zeros(P * n, **dv)
+        nxt = (1 - who) if P == 2 else who
+        nbytes += P * n * 213                                 # + the packed observation written (the step's state is not read again)
+        if case.startswith("step_obs"):
+            fn = b.lib.tetris_step_rt_observe_dev
+            args = args + (ptr(nxt), ptr(visual), ptr(vector), ptr(piece))
+        else:
+            step_fn, step_args, obs_args = fn, args, (b._h, None, n, ptr(nxt), ptr(visual), ptr(vector), ptr(piece))
+            obs_fn = b.lib.tetris_observe_packed_dev
+            def fn(*_):
+                rc = step_fn(*step_args)
+                return rc or obs_fn(*obs_args)
     unit = ("env_steps", n)
     reps = max(reps, 2048)                                   # steady state: resets of finished games inside the launches
 torch.cuda.synchronize()

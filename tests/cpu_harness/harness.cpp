@@ -411,6 +411,15 @@ int tetris_observe_packed(tetris_batch* b, const int32_t* idx, int n, const uint
 int tetris_observe_packed_dev(tetris_batch* b, const int32_t* idx, int n, const uint8_t* player, uint8_t* visual, uint8_t* vector,
                               uint8_t* piece) { return tetris_observe_packed(b, idx, n, player, visual, vector, piece); }
 
+int tetris_step_rt_observe_dev(tetris_batch* b, const uint8_t* rot, const uint8_t* trans, const uint8_t* player, int ms, uint8_t* done,
+                               uint8_t* lines, uint8_t* dead, int flags, const uint8_t* next_player, uint8_t* visual, uint8_t* vector,
+                               uint8_t* piece) {
+    if (!visual || !vector || !piece) return fail(TETRIS_E_ARG, "visual/vector/piece are NULL");
+    int rc = tetris_step_rt_dev_ex(b, rot, trans, player, ms, done, lines, dead, flags);       // (the product fuses the two kernels)
+    if (rc) return rc;
+    return tetris_observe_packed_dev(b, nullptr, b->N, next_player, visual, vector, piece);
+}
+
 int tetris_rollout_launch(tetris_batch* b, int launches, int steps_per_launch, uint32_t policy_seed, uint64_t first_step, int ms,
                           float* elapsed_ms) {
     if (launches < 1 || steps_per_launch < 0 || steps_per_launch > 256) return fail(TETRIS_E_ARG, "launches/steps_per_launch");

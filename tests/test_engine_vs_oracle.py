@@ -251,6 +251,72 @@ def test_device_side_auto_reset_and_masked_reset(kind, P):
     engines.assert_same_state(eng, ref, where="masked reset with device seeds")
 
 
+def _expected_packed(rec, me, P, H):
+    """state_dict + unpacker semantics (state_processors.py:23-54; state_unpack.py:88-137) computed from oracle records:
+    -> visual [P][n][H][10], vector [P][n][12], piece [P][n], slot 0 = player me[i]'s board"""
+    n = len(me)
+    visual, vector, piece = np.zeros((P, n, H, 10), np.uint8), np.zeros((P, n, 12), np.uint8), np.zeros((P, n), np.uint8)
+    for sl in range(P):
+        who = me if sl == 0 else (P - 1 - me)
+        r = rec[np.arange(n), who]
+        visual[sl] = (r["field"][:, :H, :] > 0).astype(np.uint8)
+        vector[sl, :, 0] = r["x"].astype(np.uint8); vector[sl, :, 1] = r["y"].astype(np.uint8); vector[sl, :, 2] = r["inc_count"]
+        vector[sl, :, 3] = np.minimum(25000, (r["combo_remaining"].astype(np.uint32) + 50) & 0xFFFF) // 100
+        vector[sl, :, 4] = r["combo_count"]
+        vector[sl, np.arange(n), 5 + r["next"]] = 1
+        piece[sl] = r["piece"]
+    return visual, vector, piece
+
+
+@pytest.mark.parametrize("kind", engines.ENGINE_PARAMS)
+@pytest.mark.parametrize("P,H", [(1, 20), (2, 20), (2, 22), (1, 21)])
+def test_step_and_observation_in_one_launch(kind, P, H):
+    """tetris_step_rt_observe_dev = one iteration of the agent loop in one launch (worker.py:91-118: perform_action, then
+    get_state + unpack): against the oracle's step (done / lines / dead, auto-reset with the schedule's seeds) and against the
+    observation the oracle's state gives for `next_player` (state_processors.py:23-54, state_unpack.py:88-137), every step;
+    n is not a multiple of the 64 games a wave holds, H = 21 runs the two-kernel fallback (odd height)."""
+    n = 4096 + 37 if kind == "hip" else 200 + 37
+    seeds = orc.episode_seed(np.arange(n), 0)
+    eng, ref = engines.make(kind, n, P, H, seeds=seeds), engines.make("oracle", n, P, H, seeds=seeds)
+    D = _DevArrays(kind)
+    rng = np.random.default_rng(5 + 10 * P + H)
+    episode = np.zeros(n, np.int64)
+    done_d, lines_d, dead_d = D.put(np.zeros(n, np.uint8)), D.put(np.zeros((P, n), np.uint8)), D.put(np.zeros((P, n), np.uint8))
+    vis_d, vec_d, pc_d = D.put(np.zeros((P, n, H, 10), np.uint8)), D.put(np.zeros((P, n, 12), np.uint8)), D.put(np.zeros((P, n), np.uint8))
+    total_done = 0
+    for s in range(120):
+        rot, trans = rng.integers(0, 4, n).astype(np.uint8), rng.integers(0, 10, n).astype(np.uint8)
+        player, nxt = rng.integers(0, P, n).astype(np.uint8), rng.integers(0, P, n).astype(np.uint8)
+        auto = s % 10 != 9
+        r_d, t_d, p_d, n_d = D.put(rot), D.put(trans), D.put(player), D.put(nxt)
+        eng.step_rt_observe_dev(D.ptr(r_d), D.ptr(t_d), D.ptr(p_d), D.ptr(done_d), D.ptr(lines_d), D.ptr(dead_d),
+                                D.ptr(n_d) if s % 7 else (None if P == 1 or not nxt.any() else D.ptr(n_d)),
+                                D.ptr(vis_d), D.ptr(vec_d), D.ptr(pc_d), auto_reset=auto)
+        d_ref = ref.step_rt(rot, trans, player)
+        rec = ref.observe()[0]
+        if kind == "hip":
+            eng.sync()
+        assert np.array_equal(D.get(done_d), d_ref), s
+        assert np.array_equal(D.get(lines_d).T, rec["reward"]) and np.array_equal(D.get(dead_d).T, rec["dead"]), s
+        idx = np.nonzero(d_ref)[0].astype(np.int32)
+        total_done += len(idx)
+        if len(idx) and auto:
+            episode[idx] += 1
+            ref.reset(idx, orc.episode_seed(idx, episode[idx]))
+        me = nxt if (s % 7 or (P > 1 and nxt.any())) else np.zeros(n, np.uint8)      # a NULL next_player means player 0
+        want_vis, want_vec, want_pc = _expected_packed(ref.observe()[0], me, P, H)
+        assert np.array_equal(D.get(pc_d), want_pc), s
+        assert np.array_equal(D.get(vec_d), want_vec), s
+        assert np.array_equal(D.get(vis_d), want_vis), s
+        if not auto:                                           # the observation above showed the finished games as they ended
+            eng.reset_dev(D.ptr(done_d), None)                 # mask = this step's done flags, seeds from the schedule
+            if len(idx):
+                episode[idx] += 1
+                ref.reset(idx, orc.episode_seed(idx, episode[idx]))
+    assert total_done > n // 4
+    engines.assert_same_state(eng, ref, where="after the fused loop")
+
+
 @pytest.mark.parametrize("kind", engines.ENGINE_PARAMS)
 def test_device_driven_loop_outlives_the_resident_rng_tables(kind):
     """An asynchronous `_dev` loop whose episodes outlive the resident RNG-table chunks (2 x 624 draws): O pieces laid side
