@@ -6,7 +6,7 @@ cd "$(dirname "$0")/.."
 SRC=gpurun_out/final; DST=profiles/r02/final
 mkdir -p $DST
 cp $SRC/bench_p1_s1.json $SRC/bench_p1_s1_driver_flags.json $SRC/bench_p2_s1.json $SRC/bench_p1_s32.json $SRC/bench_configs.json $SRC/split_stages.json $DST/
-for c in enum_planar enum_rows enum_noafter_planar observe step_auto_1p step_auto_2p; do cp $SRC/kernel_$c.json $DST/; done
+for c in enum_planar enum_rows enum_noafter_planar observe step_auto_1p step_auto_2p loop_1p step_obs_1p loop_2p step_obs_2p; do cp $SRC/kernel_$c.json $DST/; done
 cp $SRC/pytest_gpu.log $DST/pytest_gpu.txt
 cp $SRC/prof_p1.log $DST/bench_under_profiler_p1_s1.txt
 cp $SRC/prof_p1_unchained.log $DST/bench_under_profiler_p1_s1_unchained.txt
@@ -16,7 +16,7 @@ cp "$(newest $SRC/prof_p1 '*kernel_stats.csv')" $DST/kernel_stats_p1_s1.csv
 cp "$(newest $SRC/prof_p2 '*kernel_stats.csv')" $DST/kernel_stats_p2_s1.csv
 cp "$(newest $SRC/prof_p1_unchained '*kernel_stats.csv')" $DST/kernel_stats_p1_s1_unchained.csv
 cp "$(newest $SRC/prof_p2_unchained '*kernel_stats.csv')" $DST/kernel_stats_p2_s1_unchained.csv
-for c in enum_planar enum_rows enum_noafter_planar observe step_auto_1p step_auto_2p split; do cp "$(newest $SRC/prof_$c '*kernel_stats.csv')" $DST/kernel_stats_$c.csv; done
+for c in enum_planar enum_rows enum_noafter_planar observe step_auto_1p step_auto_2p loop_1p step_obs_1p loop_2p step_obs_2p split; do cp "$(newest $SRC/prof_$c '*kernel_stats.csv')" $DST/kernel_stats_$c.csv; done
 for t in p1 p2 calib; do python profiles/pmc_summary.py $SRC/pmc_$t > /dev/null; done
 cp $SRC/pmc_p1/summary.json $DST/pmc_p1_s1_summary.json
 cp $SRC/pmc_p2/summary.json $DST/pmc_p2_s1_summary.json

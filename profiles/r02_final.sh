@@ -24,7 +24,7 @@ export TETRIS_NO_CHAIN=1 TETRIS_GRAPH=1
 prof prof_p1_unchained $R/bench.py --cpu-seconds 0
 prof prof_p2_unchained $R/bench.py --cpu-seconds 0 --players 2
 unset TETRIS_NO_CHAIN TETRIS_GRAPH
-for c in enum_planar enum_rows enum_noafter_planar observe step_auto_1p step_auto_2p; do
+for c in enum_planar enum_rows enum_noafter_planar observe step_auto_1p step_auto_2p loop_1p step_obs_1p loop_2p step_obs_2p; do
   timeout -k 10 200 python profiles/kernel_prof.py $c > $O/kernel_$c.json 2>/dev/null
   prof prof_$c $R/profiles/kernel_prof.py $c
 done
