@@ -128,3 +128,62 @@ def test_zero_copy_loop_with_device_resets_and_no_host_sync():
     from tests import engines
     engines.assert_same_state(batch, ref, where="after 200 un-synchronised steps")
     batch.close()
+
+
+def test_fused_agent_loop_on_torch_tensors():
+    """The agent loop with ONE launch per iteration (TorchEnv.step_rt_observe = tetris_step_rt_observe_dev): the policy reads the
+    observation the previous iteration's launch produced, finished games are reset inside the launch, nothing synchronises with
+    the host for 200 iterations.  Afterwards the oracle replays the recorded actions; every step's outputs, every step's
+    observation (own / opponent planes, vectors, piece ids from the next player's perspective) and the final boards must agree."""
+    import importlib
+
+    import torch
+    pkg = ge.package()
+    interop = importlib.import_module("drl-tetris_amd.torch_interop")
+    n, P, H, STEPS = 4096, 2, 20, 200
+    seeds = orc.episode_seed(np.arange(n), 0)
+    batch = pkg.TetrisBatch(n, P, H, 10, seeds=seeds, device=0)
+    ref = orc.OracleBatch(n, P, H, 10, seeds=seeds)
+    env = interop.TorchEnv(batch)
+    gen = torch.Generator(device="cuda").manual_seed(23)
+    u8 = dict(dtype=torch.uint8, device="cuda")
+    h_rot, h_trans, h_me = torch.zeros(STEPS, n, **u8), torch.zeros(STEPS, n, **u8), torch.zeros(STEPS, n, **u8)
+    h_done, h_lines, h_dead = torch.zeros(STEPS, n, **u8), torch.zeros(STEPS, P, n, **u8), torch.zeros(STEPS, P, n, **u8)
+    h_vis, h_vec, h_pc = torch.zeros(STEPS, P, n, H, 10, **u8), torch.zeros(STEPS, P, n, 12, **u8), torch.zeros(STEPS, P, n, **u8)
+    me = torch.zeros(n, **u8)
+    visual, vector, piece = env.observe(me)                                            # the first decision's observation
+    for s in range(STEPS):
+        heights = visual[0].to(torch.int32).flip(1).cumsum(1).gt(0).sum(1)            # [n, W] stack heights of my board
+        trans = (heights.argmin(1) + torch.randint(0, 3, (n,), generator=gen, device="cuda")).clamp(0, 9).to(torch.uint8)
+        rot = ((piece[0] + vector[0][:, 1]) % 4).to(torch.uint8)
+        nxt = (1 - me).contiguous()                                                   # worker.py:96: the players alternate
+        h_rot[s], h_trans[s], h_me[s] = rot, trans, me
+        done, lines, dead, visual, vector, piece = env.step_rt_observe(rot, trans, me, nxt, auto_reset=True)
+        h_done[s], h_lines[s], h_dead[s] = done, lines, dead
+        h_vis[s], h_vec[s], h_pc[s] = visual, vector, piece
+        me = nxt
+    torch.cuda.synchronize()
+    rots, transs, mes = h_rot.cpu().numpy(), h_trans.cpu().numpy(), h_me.cpu().numpy()
+    dones, liness, deads = h_done.cpu().numpy(), h_lines.cpu().numpy(), h_dead.cpu().numpy()
+    viss, vecs, pcs = h_vis.cpu().numpy(), h_vec.cpu().numpy(), h_pc.cpu().numpy()
+    episode = np.zeros(n, np.int64)
+    for s in range(STEPS):
+        d_ref = ref.step_rt(rots[s], transs[s], mes[s])
+        rec = ref.observe()[0]
+        assert np.array_equal(dones[s], d_ref), s
+        assert np.array_equal(deads[s].T, rec["dead"]) and np.array_equal(liness[s].T, rec["reward"]), s
+        idx = np.nonzero(d_ref)[0].astype(np.int32)
+        if len(idx):
+            episode[idx] += 1
+            ref.reset(idx, orc.episode_seed(idx, episode[idx]))
+            rec = ref.observe()[0]
+        nxt = 1 - mes[s]
+        for sl in range(P):
+            r = rec[np.arange(n), nxt if sl == 0 else 1 - nxt]
+            assert np.array_equal(viss[s, sl], (r["field"][:, :H] > 0).astype(np.uint8)), (s, sl)
+            assert np.array_equal(pcs[s, sl], r["piece"]), (s, sl)
+            assert np.array_equal(vecs[s, sl, :, 0], r["x"].astype(np.uint8)) and np.array_equal(vecs[s, sl, :, 2], r["inc_count"]), (s, sl)
+    assert episode.sum() > n // 2
+    from tests import engines
+    engines.assert_same_state(batch, ref, where="after 200 fused iterations")
+    batch.close()
