@@ -269,12 +269,13 @@ def _expected_packed(rec, me, P, H):
 
 
 @pytest.mark.parametrize("kind", engines.ENGINE_PARAMS)
-@pytest.mark.parametrize("P,H", [(1, 20), (2, 20), (2, 22), (1, 21)])
+@pytest.mark.parametrize("P,H", [(1, 20), (2, 20), (2, 22), (1, 21), (2, 30)])
 def test_step_and_observation_in_one_launch(kind, P, H):
     """tetris_step_rt_observe_dev = one iteration of the agent loop in one launch (worker.py:91-118: perform_action, then
     get_state + unpack): against the oracle's step (done / lines / dead, auto-reset with the schedule's seeds) and against the
     observation the oracle's state gives for `next_player` (state_processors.py:23-54, state_unpack.py:88-137), every step;
-    n is not a multiple of the 64 games a wave holds, H = 21 runs the two-kernel fallback (odd height)."""
+    n is not a multiple of the 64 games a wave holds, H = 21 runs the two-kernel fallback (odd height), H = 30 needs more
+    than 48 KB of dynamic LDS per workgroup in the two-player kernel."""
     n = 4096 + 37 if kind == "hip" else 200 + 37
     seeds = orc.episode_seed(np.arange(n), 0)
     eng, ref = engines.make(kind, n, P, H, seeds=seeds), engines.make("oracle", n, P, H, seeds=seeds)
