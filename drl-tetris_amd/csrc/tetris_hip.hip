@@ -493,10 +493,11 @@ __global__ __launch_bounds__(BLOCK) void k_observe_packed(Geo geo, int n, const 
     }
 }
 
-// BASELINE config 4.  One workgroup = ENUM_BOARDS boards x 10 lanes; lane (board, xi) places the piece in column xi for the four
-// rotations in turn.  Phase A: a board's ten lanes fetch its ten columns (ONE global load per word and board) and its piece
+// BASELINE config 4.  One workgroup = one wave = ENUM_BOARDS (6) boards x 10 lanes; lane (board, xi) places the piece in column xi for
+// the four rotations in turn.  Phase A: a board's ten lanes fetch its ten columns (ONE global load per word and board) and its piece
 // word.  Phase B: they fill its BoardPre in LDS (tetris_kernels.h): band window (LDS atomics), depth strip (byte writes), prefix /
-// suffix ANDs.  Phase C: four placements per lane from ~10 LDS reads each.  16 384 boards = 2 560 waves, all resident at once.
+// suffix ANDs.  Phase C: four placements per lane from ~10 LDS reads each.  16 384 boards = 2 731 waves, all resident at once;
+// the phases are ordered inside the wave (no workgroup barrier).
 // PLANAR: rotation-minor planes — valid / land_y / cleared [n][10][4], after [10][n][10][4] (column plane c, game, column index,
 // rotation) — so that a lane's four placements are one 4-byte / 16-byte store; else the layouts tetris_enumerate_drops documents
 // ([n][4][10] and [n][4][10][10]).
@@ -507,8 +508,8 @@ __global__ __launch_bounds__(ENUM_BLOCK) void k_enumerate(Geo geo, int n, const 
     __shared__ __attribute__((aligned(16))) uint32_t s_shapes[SHAPE_WORDS];
     const int tid = threadIdx.x, b = tid / 10, j = tid - b * 10;
     const int i = blockIdx.x * ENUM_BOARDS + b;                  // board of this lane
-    const bool live = i < n;
-    uint32_t* pre = s_pre[b];
+    const bool live = b < ENUM_BOARDS && i < n;
+    uint32_t* pre = s_pre[b < ENUM_BOARDS ? b : 0];
     const uint32_t floor_bits = ~0u << H;
     if (tid < SHAPE_WORDS) s_shapes[tid] = d_shape_table.s[tid];
     uint32_t mine = 0;
@@ -522,7 +523,7 @@ __global__ __launch_bounds__(ENUM_BLOCK) void k_enumerate(Geo geo, int n, const 
         }
         if (j >= 1 && j < 5) pre[PRE_STRIP + (j - 1)] = 0u;
     }
-    __syncthreads();
+    if (ENUM_ONE_WAVE) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); else __syncthreads();
     if (live) {
         int word;
         const uint32_t bits = pre_band_bits(mine, floor_bits, j, word);
@@ -532,7 +533,7 @@ __global__ __launch_bounds__(ENUM_BLOCK) void k_enumerate(Geo geo, int n, const 
         pre[PRE_SUF + j] = pre_and_from(pre + PRE_COL, j);
         if (j == 0) { pre[PRE_PRE + NCOL] = pre_and_below(pre + PRE_COL, NCOL); pre[PRE_SUF + NCOL] = ~0u; }
     }
-    __syncthreads();
+    if (ENUM_ONE_WAVE) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); else __syncthreads();
     if (!live) return;
     const ColumnCtx cc = enum_column(pre, j);
     if (PLANAR) {

@@ -427,9 +427,13 @@ TE_HD int observe_board(const Geo& geo, size_t slot, int p, int H, uint8_t* cell
 // A placement lane then needs ~10 LDS reads and no loop over the board.
 constexpr int PRE_COL = 0, PRE_PIECE = 10, PRE_BAND = 11, PRE_STRIP = 13, PRE_PRE = 17, PRE_SUF = 28, PRE_WORDS = 40;
 #ifndef TE_ENUM_BOARDS
-#define TE_ENUM_BOARDS 32
+#define TE_ENUM_BOARDS 6
 #endif
-constexpr int ENUM_BOARDS = TE_ENUM_BOARDS, ENUM_BLOCK = ENUM_BOARDS * 10;     // boards / threads per workgroup of k_enumerate (10 lanes per board)
+// boards / threads per workgroup of k_enumerate (10 lanes per board).  6 boards = one WAVE per workgroup (60 working lanes, 4 idle):
+// the two phases of the per-board precompute are ordered within the wave and need no workgroup barrier — 7.65 -> 7.25 us on
+// C4's 16 384 boards against 32 boards (five waves, two __syncthreads) per workgroup, same box
+constexpr int ENUM_BOARDS = TE_ENUM_BOARDS, ENUM_BLOCK = ENUM_BOARDS == 6 ? 64 : ENUM_BOARDS * 10;
+constexpr bool ENUM_ONE_WAVE = ENUM_BOARDS == 6;
 
 // element functions of the per-board precompute (lane j of a board calls the ones its index selects)
 TE_HD uint32_t pre_band_bits(uint32_t col, uint32_t floor_bits, int c, int& word) {      // nibble c+2 of the 64-bit band
