@@ -229,6 +229,14 @@ int tetris_rollout_launch(tetris_batch *b, int launches, int steps_per_launch, u
  * wave never waits unboundedly (after ~50 ms it gives up, the call fails with TETRIS_E_HIP and the state is invalid).
  * on = 0: every launch on the batch's one stream.  (Environment: TETRIS_NO_CHAIN=1 sets the default to off.)           */
 int tetris_set_chained(tetris_batch *b, int on);
+/* Environment variables read by the library (measurement aids; none changes a result):
+ *   TETRIS_NO_CHAIN=1   batches are created with chained launches off (tetris_set_chained)
+ *   TETRIS_NO_DUO=1     two-player single steps through k_game<2> (both players of a game in one lane) instead of k_duo
+ *   TETRIS_GRAPH=1      un-chained rollout launches are replayed from HIP graphs of 128 kernel nodes (under rocprofv3 a plain
+ *                       launch costs the host more than the kernel takes; from a graph the profiled kernels are back to back)
+ *   TETRIS_PREQUEUE=1   (read per call) tetris_rollout_launch of <= 600 chained launches parks its streams behind a ~5 ms blocker
+ *                       kernel until every launch is queued: the GPU-paced launch period, without the host's launch cost
+ *   TETRIS_TIMING=1     tetris_rollout_launch prints its host-side costs (enqueue per launch, gate waits, until drained) to stderr */
 /* 1 if tetris_rollout_launch / tetris_rollout_random would chain launches of `steps_per_launch` steps on this batch, 0 if not
  * (switched off, caller-owned stream, split or colour batch, or two launches do not fit on the device together: a waiting
  * wave keeps its slot, so chaining is only used where it cannot keep the launch it waits for from being dispatched —
