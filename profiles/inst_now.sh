@@ -4,7 +4,7 @@ set -e -o pipefail
 O=gpurun_out/inst_now
 mkdir -p $O
 R=$GRAFT_REPO_ROOT
-timeout -k 10 300 python profiles/chain_parity.py | tail -1
+timeout -k 10 300 python tests/tools/chain_parity.py | tail -1
 python profiles/order_check.py 1 | tail -6
 (cd /tmp; export TMPDIR=/tmp; timeout -k 10 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS --kernel-trace --output-format csv -d $R/$O/pmc -- python3 $R/profiles/abl_run.py full > $R/$O/pmc.log 2>&1)
 python - <<PY

@@ -14,11 +14,11 @@ import numpy as np
 import torch
 
 import __graft_entry__ as ge
-from oracle import oracle as orc  # (seed schedule helper only)
+import importlib
 
 pkg = ge.package()
 n, steps = 65536, int(sys.argv[1]) if len(sys.argv) > 1 else 512
-seeds = orc.episode_seed(np.arange(n), 0)
+seeds = importlib.import_module("drl-tetris_amd.distributed").episode_seeds(0, n)
 B = [pkg.TetrisBatch(n, 1, 20, 10, seeds=seeds, device=0, split_side=s) for s in (0, 1)]
 stream = torch.cuda.current_stream().cuda_stream
 for b in B:
