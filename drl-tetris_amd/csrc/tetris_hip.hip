@@ -821,10 +821,15 @@ static int launch_game(tetris_batch* b, const KArgs& a) {
             return TETRIS_OK;
         }
     }
+    // (three and four players per game: the same kernel with all players of a game in one lane; it spills, and nothing is tuned for it)
     if (b->P == 1 && !b->tint) hipLaunchKernelGGL((k_game<1, MODE, false>), grid, block, 0, b->stream, a);
     else if (b->P == 1) hipLaunchKernelGGL((k_game<1, MODE, true>), grid, block, 0, b->stream, a);
-    else if (!b->tint) hipLaunchKernelGGL((k_game<2, MODE, false>), grid, block, 0, b->stream, a);
-    else hipLaunchKernelGGL((k_game<2, MODE, true>), grid, block, 0, b->stream, a);
+    else if (b->P == 2 && !b->tint) hipLaunchKernelGGL((k_game<2, MODE, false>), grid, block, 0, b->stream, a);
+    else if (b->P == 2) hipLaunchKernelGGL((k_game<2, MODE, true>), grid, block, 0, b->stream, a);
+    else if (b->P == 3 && !b->tint) hipLaunchKernelGGL((k_game<3, MODE, false>), grid, block, 0, b->stream, a);
+    else if (b->P == 3) hipLaunchKernelGGL((k_game<3, MODE, true>), grid, block, 0, b->stream, a);
+    else if (!b->tint) hipLaunchKernelGGL((k_game<4, MODE, false>), grid, block, 0, b->stream, a);
+    else hipLaunchKernelGGL((k_game<4, MODE, true>), grid, block, 0, b->stream, a);
     HIP_TRY(hipGetLastError());
     return TETRIS_OK;
 }
@@ -1022,7 +1027,8 @@ static int create_impl(tetris_batch** out, int n_games, int n_players, int heigh
     if (!out) return fail(TETRIS_E_ARG, "out is NULL");
     *out = nullptr;
     if (n_games < 1) return fail(TETRIS_E_ARG, "n_games must be >= 1");
-    if (n_players != 1 && n_players != 2) return fail(TETRIS_E_ARG, "n_players must be 1 or 2");
+    if (n_players < 1 || n_players > TETRIS_MAX_PLAYERS) return fail(TETRIS_E_ARG, "n_players must be 1..4");
+    if (n_players > 2 && split) return fail(TETRIS_E_ARG, "split batches are two-player games");
     if ((long long)n_games * n_players > (1ll << 23))       // the state allocation stays below 4 GiB (32-bit buffer offsets): 8M boards x 69 words
         return fail(TETRIS_E_ARG, "n_games * n_players must be <= 2^23");
     if (height < 4 || height > MAX_H) return fail(TETRIS_E_ARG, "height must be in [4, 31]");
@@ -1345,6 +1351,7 @@ int tetris_step_rt_observe_dev(tetris_batch* b, const uint8_t* d_rot, const uint
     if (!d_visual || !d_vector || !d_piece) return fail(TETRIS_E_ARG, "visual/vector/piece are NULL");
     if (flags & ~TETRIS_STEP_AUTO_RESET) return fail(TETRIS_E_ARG, "unknown flag");
     if (b->split) return fail(TETRIS_E_ARG, "tetris_step_rt_observe_dev is not available on split batches");
+    if (b->P > 2) return fail(TETRIS_E_ARG, "the packed observation is defined for one or two players (own / opponent's board: state_unpack.py:88-137)");
     const bool fused = !b->tint && b->H % 2 == 0 && ((uintptr_t)d_visual & 3u) == 0 && ((uintptr_t)d_vector & 3u) == 0;
     if (!fused) {             // colour batches, odd heights, unaligned outputs: the same two kernels back to back
         if ((rc = tetris_step_rt_dev_ex(b, d_rot, d_trans, d_player, ms, d_done, d_lines, d_dead, flags))) return rc;
@@ -1437,8 +1444,12 @@ int tetris_observe_records(tetris_batch* b, const int32_t* idx, int n, tetris_re
                        (uint8_t*)b->s_out0.d, (int8_t*)b->s_out1.d)
     if (b->P == 1 && !b->tint) LAUNCH_OBSERVE(1, false);
     else if (b->P == 1) LAUNCH_OBSERVE(1, true);
-    else if (!b->tint) LAUNCH_OBSERVE(2, false);
-    else LAUNCH_OBSERVE(2, true);
+    else if (b->P == 2 && !b->tint) LAUNCH_OBSERVE(2, false);
+    else if (b->P == 2) LAUNCH_OBSERVE(2, true);
+    else if (b->P == 3 && !b->tint) LAUNCH_OBSERVE(3, false);
+    else if (b->P == 3) LAUNCH_OBSERVE(3, true);
+    else if (!b->tint) LAUNCH_OBSERVE(4, false);
+    else LAUNCH_OBSERVE(4, true);
 #undef LAUNCH_OBSERVE
     HIP_TRY(hipGetLastError());
     if (records) HIP_TRY(hipMemcpyAsync(b->s_big.h, b->s_big.d, rec_bytes, hipMemcpyDeviceToHost, b->stream));
@@ -1456,6 +1467,7 @@ int tetris_observe_packed_dev(tetris_batch* b, const int32_t* d_idx, int n, cons
     int rc = check_batch(b);
     if (rc) return rc;
     if (!d_visual || !d_vector || !d_piece) return fail(TETRIS_E_ARG, "visual/vector/piece are NULL");
+    if (b->P > 2) return fail(TETRIS_E_ARG, "the packed observation is defined for one or two players (own / opponent's board: state_unpack.py:88-137)");
     if (n < 0 || (!d_idx && n > b->N)) return fail(TETRIS_E_ARG, "n out of range");
     if (n == 0) return TETRIS_OK;
     b->home_async = true;
@@ -1612,7 +1624,9 @@ int tetris_enumerate_drops_dev_ex(tetris_batch* b, const int32_t* d_idx, int n, 
 #define LAUNCH_ENUM(PP, PL) hipLaunchKernelGGL((k_enumerate<PP, PL>), grid, block, 0, b->stream, geo, n, d_idx, d_player, b->H, d_valid, \
                                                d_land_y, d_cleared, d_after)
     if (b->P == 1) { if (planar) LAUNCH_ENUM(1, true); else LAUNCH_ENUM(1, false); }
-    else { if (planar) LAUNCH_ENUM(2, true); else LAUNCH_ENUM(2, false); }
+    else if (b->P == 2) { if (planar) LAUNCH_ENUM(2, true); else LAUNCH_ENUM(2, false); }
+    else if (b->P == 3) { if (planar) LAUNCH_ENUM(3, true); else LAUNCH_ENUM(3, false); }
+    else { if (planar) LAUNCH_ENUM(4, true); else LAUNCH_ENUM(4, false); }
 #undef LAUNCH_ENUM
     HIP_TRY(hipGetLastError());
     return TETRIS_OK;
@@ -1672,8 +1686,14 @@ int tetris_get_actions(tetris_batch* b, const int32_t* idx, int n, const uint8_t
         if (b->P == 1)
             hipLaunchKernelGGL(k_actions<1>, grid, block, 0, b->stream, geo_of_batch(b), m, d_idx, d_player, b->H, (uint8_t*)s_cnt.d,
                                (uint8_t*)s_len.d, (uint8_t*)s_key.d, LANE_LISTS, max_keys, b->flags);
-        else
+        else if (b->P == 2)
             hipLaunchKernelGGL(k_actions<2>, grid, block, 0, b->stream, geo_of_batch(b), m, d_idx, d_player, b->H, (uint8_t*)s_cnt.d,
+                               (uint8_t*)s_len.d, (uint8_t*)s_key.d, LANE_LISTS, max_keys, b->flags);
+        else if (b->P == 3)
+            hipLaunchKernelGGL(k_actions<3>, grid, block, 0, b->stream, geo_of_batch(b), m, d_idx, d_player, b->H, (uint8_t*)s_cnt.d,
+                               (uint8_t*)s_len.d, (uint8_t*)s_key.d, LANE_LISTS, max_keys, b->flags);
+        else
+            hipLaunchKernelGGL(k_actions<4>, grid, block, 0, b->stream, geo_of_batch(b), m, d_idx, d_player, b->H, (uint8_t*)s_cnt.d,
                                (uint8_t*)s_len.d, (uint8_t*)s_key.d, LANE_LISTS, max_keys, b->flags);
         if (hipGetLastError() != hipSuccess) { result = fail(TETRIS_E_HIP, "k_actions launch failed"); break; }
         (void)hipMemcpyAsync(s_cnt.h, s_cnt.d, lanes, hipMemcpyDeviceToHost, b->stream);

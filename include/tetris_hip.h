@@ -20,8 +20,11 @@
  *    without synchronising (zero-copy callers, benchmarks); all others are synchronous.
  *    Host index / player arrays are validated (TETRIS_E_ARG); device-resident ones cannot be, so an
  *    out-of-range game index or player in a d_idx / d_player array is clamped into the batch by the kernel.
- *  - board height 4..31, width 10 (the reference hard-codes 10, gamePlay.cpp:202), 1 or 2 players (the reference takes
- *    any n_players, PythonHandle.cpp:5-25; none of its presets or agents uses more than two).
+ *  - board height 4..31, width 10 (the reference hard-codes 10, gamePlay.cpp:202), 1..4 players per game (the reference
+ *    takes any n_players, PythonHandle.cpp:5-25; none of its presets or agents uses more than two).  Three and four players
+ *    run through the general one-lane-per-game kernel (all of a game's players in one lane); the packed observation
+ *    (own / opponent planes), the one-launch step + observation, split batches and chained launches are one- and
+ *    two-player features.
  */
 #ifndef TETRIS_HIP_H
 #define TETRIS_HIP_H
@@ -47,6 +50,7 @@ extern "C" {
 #define TETRIS_ERR_STREAM 2u     /* the episode ran past the RNG tables: the pieces dealt in that step are wrong */
 
 #define TETRIS_MAX_H 32
+#define TETRIS_MAX_PLAYERS 4   /* players per game (PythonHandle(n_players, ...): PythonHandle.cpp:5-25) */
 #define TETRIS_W 10
 #define TETRIS_FIFO_CAP 16
 

@@ -103,8 +103,12 @@ static void run(tetris_batch* b, const KArgs& a, LaneCounters* total = nullptr) 
         if (!lane_active(a, i)) continue;
         if (b->P == 1 && !b->tint) game_body<1, MODE, false>(a, i, SHAPES.s, c);
         else if (b->P == 1) game_body<1, MODE, true>(a, i, SHAPES.s, c);
-        else if (!b->tint) game_body<2, MODE, false>(a, i, SHAPES.s, c);
-        else game_body<2, MODE, true>(a, i, SHAPES.s, c);
+        else if (b->P == 2 && !b->tint) game_body<2, MODE, false>(a, i, SHAPES.s, c);
+        else if (b->P == 2) game_body<2, MODE, true>(a, i, SHAPES.s, c);
+        else if (b->P == 3 && !b->tint) game_body<3, MODE, false>(a, i, SHAPES.s, c);
+        else if (b->P == 3) game_body<3, MODE, true>(a, i, SHAPES.s, c);
+        else if (!b->tint) game_body<4, MODE, false>(a, i, SHAPES.s, c);
+        else game_body<4, MODE, true>(a, i, SHAPES.s, c);
         sum.steps += c.steps; sum.episodes += c.episodes; sum.lines += c.lines; sum.sent += c.sent;
     }
     if (total) *total = sum;
@@ -167,7 +171,7 @@ static int create_impl(tetris_batch** out, int n_games, int n_players, int heigh
     if (!out) return fail(TETRIS_E_ARG, "out is NULL");
     *out = nullptr;
     if (n_games < 1) return fail(TETRIS_E_ARG, "n_games must be >= 1");
-    if (n_players != 1 && n_players != 2) return fail(TETRIS_E_ARG, "n_players must be 1 or 2");
+    if (n_players < 1 || n_players > TETRIS_MAX_PLAYERS) return fail(TETRIS_E_ARG, "n_players must be 1..4");
     if (height < 4 || height > MAX_H) return fail(TETRIS_E_ARG, "height must be in [4, 31]");
     if (width != NCOL) return fail(TETRIS_E_ARG, "width must be 10");
     if (!piece_map) return fail(TETRIS_E_ARG, "piece_map is NULL");
@@ -324,8 +328,12 @@ int tetris_observe_records(tetris_batch* b, const int32_t* idx, int n, tetris_re
         const Geo geo = geo_of_batch(b);
         if (b->P == 1 && !b->tint) observe_body<1, false>(geo, i, idx, b->H, SHAPES.s, records, round_over, last_winner);
         else if (b->P == 1) observe_body<1, true>(geo, i, idx, b->H, SHAPES.s, records, round_over, last_winner);
-        else if (!b->tint) observe_body<2, false>(geo, i, idx, b->H, SHAPES.s, records, round_over, last_winner);
-        else observe_body<2, true>(geo, i, idx, b->H, SHAPES.s, records, round_over, last_winner);
+        else if (b->P == 2 && !b->tint) observe_body<2, false>(geo, i, idx, b->H, SHAPES.s, records, round_over, last_winner);
+        else if (b->P == 2) observe_body<2, true>(geo, i, idx, b->H, SHAPES.s, records, round_over, last_winner);
+        else if (b->P == 3 && !b->tint) observe_body<3, false>(geo, i, idx, b->H, SHAPES.s, records, round_over, last_winner);
+        else if (b->P == 3) observe_body<3, true>(geo, i, idx, b->H, SHAPES.s, records, round_over, last_winner);
+        else if (!b->tint) observe_body<4, false>(geo, i, idx, b->H, SHAPES.s, records, round_over, last_winner);
+        else observe_body<4, true>(geo, i, idx, b->H, SHAPES.s, records, round_over, last_winner);
     }
     return TETRIS_OK;
 }
@@ -354,7 +362,9 @@ int tetris_enumerate_drops_dev_ex(tetris_batch* b, const int32_t* idx, int n, co
     if (flags & ~TETRIS_ENUM_PLANAR) return fail(TETRIS_E_ARG, "unknown flag");
     for (int i = 0; i < n; i++) {
         if (b->P == 1) enumerate_body<1>(geo_of_batch(b), i, n, idx, player, b->H, SHAPES.s, valid, land_y, cleared, after, flags & TETRIS_ENUM_PLANAR);
-        else enumerate_body<2>(geo_of_batch(b), i, n, idx, player, b->H, SHAPES.s, valid, land_y, cleared, after, flags & TETRIS_ENUM_PLANAR);
+        else if (b->P == 2) enumerate_body<2>(geo_of_batch(b), i, n, idx, player, b->H, SHAPES.s, valid, land_y, cleared, after, flags & TETRIS_ENUM_PLANAR);
+        else if (b->P == 3) enumerate_body<3>(geo_of_batch(b), i, n, idx, player, b->H, SHAPES.s, valid, land_y, cleared, after, flags & TETRIS_ENUM_PLANAR);
+        else enumerate_body<4>(geo_of_batch(b), i, n, idx, player, b->H, SHAPES.s, valid, land_y, cleared, after, flags & TETRIS_ENUM_PLANAR);
     }
     return TETRIS_OK;
 }
@@ -373,7 +383,9 @@ int tetris_get_actions(tetris_batch* b, const int32_t* idx, int n, const uint8_t
     std::vector<uint8_t> hc(lanes), hl(lanes * LANE_LISTS), hk(lanes * LANE_LISTS * max_keys);
     for (size_t t = 0; t < lanes; t++) {
         if (b->P == 1) actions_body<1>(geo_of_batch(b), t, idx, player, b->H, SHAPES.s, hc.data(), hl.data(), hk.data(), LANE_LISTS, max_keys, b->flags);
-        else actions_body<2>(geo_of_batch(b), t, idx, player, b->H, SHAPES.s, hc.data(), hl.data(), hk.data(), LANE_LISTS, max_keys, b->flags);
+        else if (b->P == 2) actions_body<2>(geo_of_batch(b), t, idx, player, b->H, SHAPES.s, hc.data(), hl.data(), hk.data(), LANE_LISTS, max_keys, b->flags);
+        else if (b->P == 3) actions_body<3>(geo_of_batch(b), t, idx, player, b->H, SHAPES.s, hc.data(), hl.data(), hk.data(), LANE_LISTS, max_keys, b->flags);
+        else actions_body<4>(geo_of_batch(b), t, idx, player, b->H, SHAPES.s, hc.data(), hl.data(), hk.data(), LANE_LISTS, max_keys, b->flags);
     }
     if (b->flags[F_BADARG]) { b->flags[F_BADARG] = 0; return fail(TETRIS_E_ARG, "output capacity exceeded"); }
     for (int i = 0; i < n; i++) {
@@ -397,6 +409,7 @@ int tetris_get_actions(tetris_batch* b, const int32_t* idx, int n, const uint8_t
 int tetris_observe_packed(tetris_batch* b, const int32_t* idx, int n, const uint8_t* player, uint8_t* visual, uint8_t* vector,
                           uint8_t* piece) {
     int rc = check_idx(b, idx, n); if (rc) return rc;
+    if (b->P > 2) return fail(TETRIS_E_ARG, "the packed observation is defined for one or two players (own / opponent's board: state_unpack.py:88-137)");
     const int cells = b->H * NCOL;
     for (int sl = 0; sl < b->P; sl++)
         for (int i = 0; i < n; i++) {

@@ -177,6 +177,12 @@ TRACES = {
     # lift the freshly dealt piece any more (gamePlay.cpp:179-192 pushGarbage -> death) or the spawn collides
     "garbage_flood_2p": dict(P=2, H=20, pieces=[6, 4], seed0=23, steps=2500, policy="greedy", sloppiness=0.02, solo=0),
     "garbage_flood_2p_12": dict(P=2, H=12, pieces=[6], seed0=8, steps=1500, policy="greedy", sloppiness=0.0, solo=0),
+    # more than two players (PythonHandle.cpp:5-25, distributeLines :124-136: every opponent receives amount / (P - 1) lines as a
+    # float — halves with three players, thirds with four — and the round ends when fewer than two are alive)
+    "rt_3p": dict(P=3, H=20, pieces="all", seed0=1000, steps=2400, policy="rt"),
+    "keys_4p": dict(P=4, H=20, pieces="all", seed0=12, steps=2000, policy="keys"),
+    "greedy_3p_io": dict(P=3, H=20, pieces=[6, 4], seed0=5, steps=2400, policy="greedy", sloppiness=0.03),
+    "greedy_4p_o": dict(P=4, H=20, pieces=[6], seed0=19, steps=2400, policy="greedy", sloppiness=0.03),
 }
 
 

@@ -251,6 +251,65 @@ def test_device_side_auto_reset_and_masked_reset(kind, P):
     engines.assert_same_state(eng, ref, where="masked reset with device seeds")
 
 
+@pytest.mark.parametrize("kind", engines.ENGINE_PARAMS)
+@pytest.mark.parametrize("P", [3, 4])
+def test_three_and_four_players(kind, P):
+    """More than two players per game (PythonHandle(n_players, ...), PythonHandle.cpp:5-25; distributeLines gives every opponent
+    amount / (P - 1) lines as a float, :124-136; the round ends when fewer than two players are alive): (r, t) steps and raw key
+    lists for random players with resets, enumeration and get_actions for the last player, snapshot / restore, the built-in
+    rollout — all against the oracle, which the reference's own 3- and 4-player traces pin (tests/golden/trace_*_3p / _4p)."""
+    n = 2048 if kind == "hip" else 160
+    seeds = orc.episode_seed(np.arange(n), 0)
+    eng, ref = engines.make(kind, n, P, 20, (6, 4), seeds=seeds), engines.make("oracle", n, P, 20, (6, 4), seeds=seeds)
+    rng = np.random.default_rng(100 + P)
+    episode = np.zeros(n, np.int64)
+    blob, blob_ref, total_done = None, None, 0
+    for s in range(300):
+        player = rng.integers(0, P, n).astype(np.uint8)
+        if s % 3 == 2:                                         # raw key lists for every player of every game
+            lens = rng.integers(0, 6, (n, P)).astype(np.uint8)
+            keys = rng.integers(0, 11, (n, P, 6)).astype(np.uint8)
+            keys[np.arange(n), player, np.maximum(lens[np.arange(n), player], 1) - 1] = 7
+            lens[np.arange(n), player] = np.maximum(lens[np.arange(n), player], 1)
+            d1 = eng.step_keys(keys, lens)[0]
+            ref.make_actions(keys, lens)
+            d2 = ref.finish_actions(400)
+        else:                                                  # O and I pieces laid side by side: lines, combos, garbage thirds / halves
+            trans = np.where(rng.random(n) < 0.1, rng.integers(0, 10, n), 2 * ((s // P + np.arange(n)) % 5)).astype(np.uint8)
+            rot = (rng.random(n) < 0.1).astype(np.uint8)
+            d1, d2 = eng.step_rt(rot, trans, player), ref.step_rt(rot, trans, player)
+        assert np.array_equal(d1, d2), s
+        if s == 120:
+            blob, blob_ref = eng.snapshot(), engines.make("oracle", n, P, 20, (6, 4))
+            blob_ref.copy_from(ref)
+        idx = np.nonzero(d2)[0].astype(np.int32)
+        total_done += len(idx)
+        if len(idx):
+            episode[idx] += 1
+            sd = orc.episode_seed(idx, episode[idx])
+            eng.reset(idx, sd); ref.reset(idx, sd)
+        if s % 60 == 59:
+            engines.assert_same_state(eng, ref, where=f"step {s}")
+    rec = ref.observe()[0]
+    assert rec["lines_sent"].sum() > 0 and (rec["incoming"] % 1 != 0).any() or rec["lines_blocked"].sum() > 0     # fractional garbage was in play
+    last = np.full(n, P - 1, np.uint8)
+    v1, y1, c1, a1 = eng.enumerate_drops(player=last)
+    v2, y2, c2, a2 = ref.enumerate_drops(player=last)
+    ok = v2.astype(bool)
+    assert np.array_equal(v1, v2) and np.array_equal(y1[ok], y2[ok]) and np.array_equal(c1[ok], c2[ok])
+    sub = np.arange(0, n, 37, dtype=np.int32)
+    assert eng.get_actions(sub, player=P - 1) == [ref.get_actions(int(g), P - 1) for g in sub]
+    with pytest.raises(Exception):
+        eng.observe_packed(player=0)                           # own / opponent planes: two players at most
+    eng.restore(blob); ref.copy_from(blob_ref)
+    engines.assert_same_state(eng, ref, where="restored at step 120")
+    c_gpu, _ = eng.rollout_random(40, 2, first_step=7)
+    _, c_ref = ref.rollout_random(80, first_step=7)
+    assert c_gpu.tolist() == c_ref.tolist()
+    engines.assert_same_state(eng, ref, where="after the built-in rollout")
+    assert total_done > 0
+
+
 def _expected_packed(rec, me, P, H):
     """state_dict + unpacker semantics (state_processors.py:23-54; state_unpack.py:88-137) computed from oracle records:
     -> visual [P][n][H][10], vector [P][n][12], piece [P][n], slot 0 = player me[i]'s board"""
