@@ -43,7 +43,7 @@ def test_no_cpu_fallback_without_device():
 def test_argument_validation_through_the_harness():
     pkg = ge.package()
     h = ge.build_harness()
-    for kw in (dict(n_players=3), dict(height=40), dict(width=12), dict(pieces=[9])):
+    for kw in (dict(n_players=5), dict(n_players=0), dict(height=40), dict(width=12), dict(pieces=[9])):
         args = dict(n_games=2, n_players=2, height=20, width=10, pieces=[0, 1, 2, 3, 4, 5, 6])
         args.update(kw)
         with pytest.raises(pkg.TetrisError):
