@@ -215,6 +215,9 @@ def main():
         try:
             shard.run(64, S)
             gpu_paced_us = min(shard.run(512, S)["event_ms"] for _ in range(2)) * 1e3 / 512
+        except Exception as e:                                   # (an extra, never a reason to lose the line)
+            print(f"bench: GPU-paced extra run failed: {e}", file=sys.stderr)
+            gpu_paced_us = None
         finally:
             del os.environ["TETRIS_PREQUEUE"]
     # chained launches (include/tetris_hip.h: tetris_set_chained): on by default where two launches fit on the device together —
