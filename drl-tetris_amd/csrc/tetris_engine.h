@@ -54,8 +54,8 @@ TE_HD void st_stream(uint32_t* p, uint32_t v) { *p = v; }
 // Diagnostic build only (-DTE_PHASE_TRACE, profiles/phase_trace.py): the first active lane of a wave writes the shader
 // clock at phase boundaries into a device buffer.  Product builds compile TE_STAMP to nothing.
 #if defined(TE_PHASE_TRACE) && defined(__HIPCC__)
-__device__ unsigned long long d_trace[2048 * 16];
-__device__ unsigned long long d_chain_trace[8 * 1024 * 8];
+static __device__ unsigned long long d_trace[2048 * 16];            // (one copy per translation unit; read out by tetris_hip.hip)
+static __device__ unsigned long long d_chain_trace[8 * 1024 * 8];
 #endif
 #if defined(TE_PHASE_TRACE) && defined(__HIP_DEVICE_COMPILE__)
 __device__ __forceinline__ void te_stamp(int k, bool realtime = false) {

@@ -22,37 +22,7 @@ using namespace te;
 
 // ============================================================================ device side
 
-__device__ const ShapeTable d_shape_table = make_shape_table();
-
-template <int P, int MODE, bool TINT>
-__global__ __launch_bounds__(256) void k_game(KArgs a) {
-    // Shape table in LDS, one private 128-byte copy per wave: no workgroup barrier, so a wave starts computing as soon as
-    // the state words it needs first have arrived instead of waiting for all loads of all four waves.  The table load is
-    // issued before the state loads (loads return in order), and ds_write -> ds_read order within a wave is by lgkmcnt.
-    __shared__ __attribute__((aligned(16))) uint32_t s_shapes_all[4][SHAPE_WORDS];
-    uint32_t* s_shapes = s_shapes_all[threadIdx.x >> 6];
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool active = lane_active(a, i);
-    LaneCounters cnt = {0, 0, 0, 0};                   // (per-lane sums feed the CPU test harness only)
-    TE_STAMP(0); TE_STAMP_RT(1);
-    const uint32_t shape_word = d_shape_table.s[threadIdx.x & 63];
-    Game<P> g;
-    if (active) game_load<P, MODE, TINT>(a, i, g);
-    TE_STAMP(2);
-#if defined(TE_PHASE_TRACE) && TE_PHASE_TRACE == 2
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // variant: time until ALL state words have arrived
-    TE_STAMP(3);
-#endif
-    s_shapes[threadIdx.x & 63] = shape_word;
-    __builtin_amdgcn_wave_barrier();
-    if (active) game_run<P, MODE, TINT>(a, i, s_shapes, g, cnt);
-    TE_STAMP(9);
-#if defined(TE_PHASE_TRACE) && TE_PHASE_TRACE == 3
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // variant: time until all stores are acknowledged
-    TE_STAMP(10);
-#endif
-    TE_STAMP(14); TE_STAMP_RT(15);
-}
+#include "tetris_game_kernel.h"
 
 // Chained launches of the built-in rollout (one env-step per launch).  A game's step E depends on nothing but the same game's
 // step E - 1, yet launches on one stream are separated by a full barrier: launch E waits for the SLOWEST wave of launch E - 1
@@ -826,10 +796,7 @@ static int launch_game(tetris_batch* b, const KArgs& a) {
     else if (b->P == 1) hipLaunchKernelGGL((k_game<1, MODE, true>), grid, block, 0, b->stream, a);
     else if (b->P == 2 && !b->tint) hipLaunchKernelGGL((k_game<2, MODE, false>), grid, block, 0, b->stream, a);
     else if (b->P == 2) hipLaunchKernelGGL((k_game<2, MODE, true>), grid, block, 0, b->stream, a);
-    else if (b->P == 3 && !b->tint) hipLaunchKernelGGL((k_game<3, MODE, false>), grid, block, 0, b->stream, a);
-    else if (b->P == 3) hipLaunchKernelGGL((k_game<3, MODE, true>), grid, block, 0, b->stream, a);
-    else if (!b->tint) hipLaunchKernelGGL((k_game<4, MODE, false>), grid, block, 0, b->stream, a);
-    else hipLaunchKernelGGL((k_game<4, MODE, true>), grid, block, 0, b->stream, a);
+    else if (tetris_launch_game_multi(b->P, b->tint, MODE, grid, block, b->stream, a)) return fail(TETRIS_E_ARG, "no kernel for this player count / mode");
     HIP_TRY(hipGetLastError());
     return TETRIS_OK;
 }

@@ -6,7 +6,7 @@ epoch published.  Prints per-phase medians and, per wave, the distance between c
 and the hand-off gap: publication by launch E-1 -> "epoch seen" by launch E.
 
     hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -DTE_PHASE_TRACE=1 -I include \
-          -o profiles/_ab/lib_trace1.so drl-tetris_amd/csrc/tetris_hip.hip
+          -o profiles/_ab/lib_trace1.so drl-tetris_amd/csrc/tetris_hip.hip drl-tetris_amd/csrc/tetris_hip_multi.hip
     python profiles/chain_trace.py profiles/_ab/lib_trace1.so
 """
 import ctypes as C

@@ -6,7 +6,7 @@ tetris_engine.h:te_stamp) and prints, over all 1024 waves of ONE launch in the m
   * per-phase durations in shader-clock cycles (median / p10 / p90 over waves).
 
     hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -DTE_PHASE_TRACE=1 -I include \
-          -o profiles/_ab/lib_trace1.so drl-tetris_amd/csrc/tetris_hip.hip
+          -o profiles/_ab/lib_trace1.so drl-tetris_amd/csrc/tetris_hip.hip drl-tetris_amd/csrc/tetris_hip_multi.hip
     python profiles/phase_trace.py profiles/_ab/lib_trace1.so [P [S]]
 """
 import ctypes as C
