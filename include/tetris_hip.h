@@ -231,6 +231,9 @@ int tetris_rollout_launch(tetris_batch *b, int launches, int steps_per_launch, u
  * launch waits for the slowest wave of the whole previous launch plus the kernel boundary).  Results are bit-identical.
  * A wave that waits keeps its slot; launches are therefore chained only while two of them fit on the device together, and a
  * wave never waits unboundedly (after ~50 ms it gives up, the call fails with TETRIS_E_HIP and the state is invalid).
+ * The fit is computed for a device this process has to itself: kernels of OTHER processes that occupy wave slots of the same
+ * GPU can keep a launch from fitting beside its successor; the waiting waves then give up after their bound and the call
+ * fails as above (nothing hangs) — share a GPU between processes with chaining off.
  * on = 0: every launch on the batch's one stream.  (Environment: TETRIS_NO_CHAIN=1 sets the default to off.)           */
 int tetris_set_chained(tetris_batch *b, int on);
 /* Environment variables read by the library (measurement aids; none changes a result):
