@@ -93,7 +93,11 @@ TE_HD void report_status(const KArgs& a, uint32_t st) {
 
 // ---- chained launches (tetris_hip.hip: k_chain): the hand-over of a wave's 64 games from launch E - 1 to launch E
 constexpr uint32_t CHAIN_POISON = 0xFFFFFFFFu;      // a wave gave up waiting: every later launch's wave passes the poison on
-constexpr int CHAIN_SPIN_LIMIT = 1 << 21;           // polls before a wave gives up (each ~1 us with its short sleep): ~2 s
+#ifndef TE_CHAIN_SLEEP
+#define TE_CHAIN_SLEEP 32           // s_sleep between two polls of the epoch word (x 64 cycles).  GPU-paced periods, alternating processes
+                                  // (profiles/r02/chain_sleep_ab.txt): 2: 4.70-4.77 us, 8: 4.72-4.74, 16: 4.62-4.71, 32: 4.64-4.72, 64: 4.96
+#endif
+constexpr int CHAIN_SPIN_LIMIT = 1 << 21;           // polls before a wave gives up (each ~1.3 us with its sleep): ~3 s
 
 // true when the state of this wave's games as launch E - 1 left it is visible (their stores were `sc1` and drained before the
 // epoch word was written, and the word is polled with an `sc1` load: MI355X_MICROARCH.md, valid forms of an inter-workgroup hand-off)
@@ -104,7 +108,7 @@ TE_HD bool chain_wait(const KArgs& a, uint32_t wave) {
         if (v == want) return true;
         if (v == CHAIN_POISON) break;
 #if defined(__HIP_DEVICE_COMPILE__)
-        __builtin_amdgcn_s_sleep(2);
+        __builtin_amdgcn_s_sleep(TE_CHAIN_SLEEP);
 #endif
     }
     return false;

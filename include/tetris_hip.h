@@ -230,7 +230,7 @@ int tetris_rollout_launch(tetris_batch *b, int launches, int steps_per_launch, u
  * of the previous launch publishes after its state stores have drained — instead of per launch by the stream (where every
  * launch waits for the slowest wave of the whole previous launch plus the kernel boundary).  Results are bit-identical.
  * A wave that waits keeps its slot; launches are therefore chained only while two of them fit on the device together, and a
- * wave never waits unboundedly (after ~50 ms it gives up, the call fails with TETRIS_E_HIP and the state is invalid).
+ * wave never waits unboundedly (after ~3 s it gives up, the call fails with TETRIS_E_HIP and the state is invalid).
  * The fit is computed for a device this process has to itself: kernels of OTHER processes that occupy wave slots of the same
  * GPU can keep a launch from fitting beside its successor; the waiting waves then give up after their bound and the call
  * fails as above (nothing hangs) — share a GPU between processes with chaining off.
