@@ -57,7 +57,7 @@ __global__ __launch_bounds__(64) void k_chain(KArgs a) {
     const uint32_t d0 = g.draw0, d1 = g.draw1;
     TE_STAMP_CHAIN(a.epoch, 1);
     if (!chain_wait(a, (uint32_t)wave)) {
-        if (lane == 0) { ((volatile uint32_t*)a.status)[F_CHAIN] = 1u; st_agent(a.chain + wave, CHAIN_POISON); }
+        if (lane == 0) { ((volatile uint32_t*)a.status)[F_CHAIN] = 1u; st_agent(a.chain + (size_t)wave * CHAIN_STRIDE, CHAIN_POISON); }
         return;
     }
     TE_STAMP_CHAIN(a.epoch, 2);
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(64) void k_chain(KArgs a) {
     TE_STAMP_CHAIN(a.epoch, 4);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every store (and counter atomic) of this wave has been acknowledged
     TE_STAMP_CHAIN(a.epoch, 5);
-    if (lane == 0) st_agent(a.chain + wave, a.epoch);
+    if (lane == 0) st_agent(a.chain + (size_t)wave * CHAIN_STRIDE, a.epoch);
     TE_STAMP_CHAIN(a.epoch, 6);
 }
 
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256) void k_duo(KArgs a) {
     if (CHAIN) {
         if (active) policy_draw(a, (uint32_t)gi, a.first_step, pd0, pd1);        // while the wave waits for its predecessor
         if (!chain_wait(a, (uint32_t)wave)) {
-            if (lane == 0) { ((volatile uint32_t*)a.status)[F_CHAIN] = 1u; st_agent(a.chain + wave, CHAIN_POISON); }
+            if (lane == 0) { ((volatile uint32_t*)a.status)[F_CHAIN] = 1u; st_agent(a.chain + (size_t)wave * CHAIN_STRIDE, CHAIN_POISON); }
             return;
         }
     }
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256) void k_duo(KArgs a) {
     }
     if (CHAIN) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every store (and counter atomic) of this wave has been acknowledged
-        if (lane == 0) st_agent(a.chain + wave, a.epoch);
+        if (lane == 0) st_agent(a.chain + (size_t)wave * CHAIN_STRIDE, a.epoch);
     }
     if (OBS) {
         const int pitch = a.H * NCOL / 4, first = wave * 32;
@@ -1034,7 +1034,7 @@ static int create_impl(tetris_batch** out, int n_games, int n_players, int heigh
     for (int k = 0; k < CHAIN_STREAMS; k++) CREATE_TRY(hipStreamCreateWithFlags(&b->chain_stream[k], hipStreamNonBlocking));
     for (int k = 0; k < 3; k++) CREATE_TRY(hipEventCreateWithFlags(&b->chain_ev[k], hipEventDisableTiming));
     {
-        const size_t chain_bytes = (((size_t)n_games + 15) / 16) * sizeof(uint32_t);       // (one word per wave; at least 16 games per wave)
+        const size_t chain_bytes = (((size_t)n_games + 15) / 16) * sizeof(uint32_t) * CHAIN_STRIDE;       // (one word per wave; at least 16 games per wave)
         CREATE_TRY(hipMalloc((void**)&b->d_chain, chain_bytes));
         CREATE_TRY(hipMemsetAsync(b->d_chain, 0, chain_bytes, b->stream));
     }

@@ -93,18 +93,25 @@ TE_HD void report_status(const KArgs& a, uint32_t st) {
 
 // ---- chained launches (tetris_hip.hip: k_chain): the hand-over of a wave's 64 games from launch E - 1 to launch E
 constexpr uint32_t CHAIN_POISON = 0xFFFFFFFFu;      // a wave gave up waiting: every later launch's wave passes the poison on
-#ifndef TE_CHAIN_SLEEP
-#define TE_CHAIN_SLEEP 32           // s_sleep between two polls of the epoch word (x 64 cycles).  GPU-paced periods, alternating processes
-                                  // (profiles/r02/chain_sleep_ab.txt): 2: 4.70-4.77 us, 8: 4.72-4.74, 16: 4.62-4.71, 32: 4.64-4.72, 64: 4.96
+// The epoch words of consecutive waves lie CHAIN_STRIDE words apart: one 128-byte line per wave.  Packed (32 waves' words in
+// one line) every publication hit a line that 31 other waves were polling: GPU-paced 4.72 us per launch against 4.50 with one
+// line each at the same poll interval, and with the lines private a SHORT poll interval pays (s_sleep 32: 4.50, 8: 4.24,
+// 0-2: 4.13-4.15 us; packed it had been the other way round: profiles/r02/chain_sleep_ab.txt, chain_stride_ab.txt).
+#ifndef TE_CHAIN_STRIDE
+#define TE_CHAIN_STRIDE 32
 #endif
-constexpr int CHAIN_SPIN_LIMIT = 1 << 21;           // polls before a wave gives up (each ~1.3 us with its sleep): ~3 s
+constexpr int CHAIN_STRIDE = TE_CHAIN_STRIDE;
+#ifndef TE_CHAIN_SLEEP
+#define TE_CHAIN_SLEEP 1            // s_sleep between two polls of the epoch word (x 64 cycles)
+#endif
+constexpr int CHAIN_SPIN_LIMIT = 1 << 22;           // polls before a wave gives up (each ~0.5 us: an agent-scope load + a short sleep): ~2 s
 
 // true when the state of this wave's games as launch E - 1 left it is visible (their stores were `sc1` and drained before the
 // epoch word was written, and the word is polled with an `sc1` load: MI355X_MICROARCH.md, valid forms of an inter-workgroup hand-off)
 TE_HD bool chain_wait(const KArgs& a, uint32_t wave) {
     const uint32_t want = a.epoch - 1u;
     for (int spin = 0; spin < CHAIN_SPIN_LIMIT; spin++) {
-        const uint32_t v = ld_agent(a.chain + wave);
+        const uint32_t v = ld_agent(a.chain + (size_t)wave * CHAIN_STRIDE);
         if (v == want) return true;
         if (v == CHAIN_POISON) break;
 #if defined(__HIP_DEVICE_COMPILE__)
