@@ -26,8 +26,8 @@ using namespace te;
 
 // Chained launches of the built-in rollout (one env-step per launch).  A game's step E depends on nothing but the same game's
 // step E - 1, yet launches on one stream are separated by a full barrier: launch E waits for the SLOWEST wave of launch E - 1
-// plus the kernel boundary (~1.4 us of a ~5.7 us launch period, profiles/).  Here consecutive launches go to two streams
-// alternately, so launch E is dispatched while E - 1 still runs, and the dependence is enforced per WAVE (one workgroup = one
+// plus the kernel boundary (~1.4 us of a ~5.7 us launch period, profiles/).  Here consecutive launches rotate over CHAIN_STREAMS (3)
+// streams, so launch E is dispatched while E - 1 and E - 2 still run, and the dependence is enforced per WAVE (one workgroup = one
 // wave = 64 games): wave w of launch E polls an epoch word until wave w of launch E - 1 has published E - 1.  Every state
 // load / store is agent-scope (`sc1`: written through, read past the per-XCD L2), the storing wave drains its stores
 // (`s_waitcnt vmcnt(0)`) before it publishes — the measured-valid hand-off of MI355X_MICROARCH.md.  Spins are bounded: a wave
@@ -37,7 +37,9 @@ using namespace te;
 #endif
 constexpr int CHAIN_LANES = TE_CHAIN_LANES;
 #ifndef TE_CHAIN_STREAMS
-#define TE_CHAIN_STREAMS 2         // streams the chained launches rotate over = launches in flight (experiment knob)
+#define TE_CHAIN_STREAMS 3         // streams the chained launches rotate over = launches in flight.  3 x 1024 waves of 64k single-player
+                                   // boards fit in the 15 x 256 wave slots chain_fits counts; GPU-paced 4.02 us per launch against 4.14 with 2
+                                   // (with the epoch words still packed 32 to a line it had been 4.9-5.06 against 4.71-4.80)
 #endif
 constexpr int CHAIN_STREAMS = TE_CHAIN_STREAMS;
 template <int P>
@@ -801,9 +803,10 @@ static int launch_game(tetris_batch* b, const KArgs& a) {
     return TETRIS_OK;
 }
 
-// Chained launches are deadlock-free only if the waves of two consecutive launches can be resident together: the waves of
+// Chained launches are deadlock-free only if the waves of all launches in flight can be resident together: the waves of
 // launch E spin (in their slots) until the same waves of launch E - 1 have published, so E - 1 must never be short of a slot
-// because of them.  At most two launches are in flight (E + 1 follows E - 1 on the same stream).  The occupancy API can be
+// because of them.  At most CHAIN_STREAMS launches are in flight (E follows E - CHAIN_STREAMS on its stream, so the oldest
+// launch in flight never waits for an epoch: its predecessor has completed).  The occupancy API can be
 // one workgroup per CU too high for kernels of this SGPR count (MI355X_MICROARCH.md, correctness boundaries): one is
 // subtracted.  64k single-player boards: 1 024 waves per launch, 15 x 256 slots.  64k two-player boards (k_duo, 220
 // VGPRs: 8 waves per CU): 2 048 waves per launch, 7 x 256 slots — does not fit, those launches stay on one stream.
@@ -1736,9 +1739,9 @@ int tetris_rollout_launch(tetris_batch* b, int launches, int steps_per_launch, u
     group = group < 1 ? 1 : (group > GATE_GROUP ? GATE_GROUP : group);
     const uint32_t need = (uint32_t)(2 * steps_per_launch * (2 * group + 2) + 16);
     if (b->margin < need) b->margin = need;
-    // batches on their own stream: chained launches (k_chain / k_duo<.., true>) — consecutive launches alternate between two
+    // batches on their own stream: chained launches (k_chain / k_duo<.., true>) — consecutive launches rotate over CHAIN_STREAMS
     // streams and each wave waits for its own predecessor only, not for the slowest wave of the whole previous launch.
-    // Only when TWO launches fit on the device together (chain_fits): a waiting wave keeps its slot, so a launch whose waves
+    // Only when CHAIN_STREAMS launches fit on the device together (chain_fits): a waiting wave keeps its slot, so a launch whose waves
     // wait must never be able to keep its predecessor's waves from being dispatched.
     const bool chained = rollout_chained(b, steps_per_launch) && chain_acquire(b);
     struct ChainGuard {                           // (released on every return path; the call ends with both chain streams drained)

@@ -225,11 +225,11 @@ int tetris_rollout_launch(tetris_batch *b, int launches, int steps_per_launch, u
                           uint64_t first_step, int ms, float *elapsed_ms);
 
 /* Chained launches of the built-in rollout (default on; single-player batches on their own stream, one or more steps per
- * launch): a game's step E depends only on the same game's step E - 1, so consecutive launches are put on two streams
- * alternately and ordered per WAVE — the 64 games of a wave wait, inside the kernel, for an epoch word that the same wave
+ * launch): a game's step E depends only on the same game's step E - 1, so consecutive launches rotate over three streams
+ * and are ordered per WAVE — the 64 games of a wave wait, inside the kernel, for an epoch word that the same wave
  * of the previous launch publishes after its state stores have drained — instead of per launch by the stream (where every
  * launch waits for the slowest wave of the whole previous launch plus the kernel boundary).  Results are bit-identical.
- * A wave that waits keeps its slot; launches are therefore chained only while two of them fit on the device together, and a
+ * A wave that waits keeps its slot; launches are therefore chained only while three of them fit on the device together, and a
  * wave never waits unboundedly (after ~3 s it gives up, the call fails with TETRIS_E_HIP and the state is invalid).
  * The fit is computed for a device this process has to itself: kernels of OTHER processes that occupy wave slots of the same
  * GPU can keep a launch from fitting beside its successor; the waiting waves then give up after their bound and the call
@@ -245,7 +245,7 @@ int tetris_set_chained(tetris_batch *b, int on);
  *                       kernel until every launch is queued: the GPU-paced launch period, without the host's launch cost
  *   TETRIS_TIMING=1     tetris_rollout_launch prints its host-side costs (enqueue per launch, gate waits, until drained) to stderr */
 /* 1 if tetris_rollout_launch / tetris_rollout_random would chain launches of `steps_per_launch` steps on this batch, 0 if not
- * (switched off, caller-owned stream, split or colour batch, or two launches do not fit on the device together: a waiting
+ * (switched off, caller-owned stream, split or colour batch, or three launches do not fit on the device together: a waiting
  * wave keeps its slot, so chaining is only used where it cannot keep the launch it waits for from being dispatched —
  * 64k single-player boards fit, 64k two-player boards do not).                                                          */
 int tetris_rollout_is_chained(tetris_batch *b, int steps_per_launch);

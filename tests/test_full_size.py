@@ -114,9 +114,9 @@ def test_batch_independence_and_order_invariance():
     assert a.snapshot().tobytes() == blob.tobytes()
 
 
-def test_chained_launches_bit_exact_and_only_where_two_launches_fit():
+def test_chained_launches_bit_exact_and_only_where_the_launches_in_flight_fit():
     """Chained rollout launches (tetris_set_chained: two streams, per-wave epoch words) against the oracle, switching the mode
-    back and forth in one batch; the library chains only where two launches fit on the device together."""
+    back and forth in one batch; the library chains only where the launches in flight (three) fit on the device together."""
     n = 65536
     seeds = orc.episode_seed(np.arange(n), 0)
     eng = engines.make("hip", n, 1, seeds=seeds)
@@ -134,7 +134,7 @@ def test_chained_launches_bit_exact_and_only_where_two_launches_fit():
     assert total.tolist() == want.tolist()
     for lo in range(0, n, 8192):
         engines.assert_same_state(eng, ref, idx=np.arange(lo, lo + 8192, dtype=np.int32), where=f"games {lo}..")
-    # two-player boards: the duo kernel needs 220 VGPRs, two launches of 64k games do not fit together -> not chained; 8k games do
+    # two-player boards: three launches of 64k games (2048 waves each) do not fit on the device together -> not chained; 8k games do
     big = engines.make("hip", n, 2, seeds=seeds)
     assert not big.rollout_is_chained(1)
     m = 8192
