@@ -741,7 +741,7 @@ struct tetris_batch {
     hipStream_t own_stream = nullptr;
     // chained launches (k_chain): two extra streams, one epoch word per wave, the number of the last chained launch
     hipStream_t chain_stream[CHAIN_STREAMS] = {};
-    hipEvent_t chain_ev[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t chain_ev[CHAIN_STREAMS + 1] = {};      // [k]: end of chain stream k's last launch (join); [CHAIN_STREAMS]: fork from the batch's stream
     uint32_t* d_chain = nullptr;
     uint32_t chain_epoch = 0;
     int use_chain = 1;                   // TETRIS_NO_CHAIN=1 in the environment: every rollout launch on the batch's one stream
@@ -874,17 +874,18 @@ static hipError_t drain_stream(hipStream_t st) {
 }
 
 // drain the batch's stream(s), then the flag words: sticky errors surface, the RNG tables are extended when a board came close to their end
-static int finish_call(tetris_batch* b) {
+// `drained`: the caller has already seen an event complete that is ordered behind everything the batch's streams held (a stream
+// query makes the runtime push a marker through the queue and wait for it: ~6 us per stream even when the stream is idle)
+static int finish_call(tetris_batch* b, bool drained = false) {
     if (!b->busy && !b->chain_pending && b->stream == b->own_stream) {      // drained already and nothing enqueued since: only the flag words
         int rc0 = service_flags(b);
         if (rc0) return rc0;
         if (!b->busy) return TETRIS_OK;           // (an extension would have enqueued work)
     }
-    if (b->chain_pending) {
+    if (b->chain_pending && !drained)
         for (int k = 0; k < CHAIN_STREAMS; k++) HIP_TRY(drain_stream(b->chain_stream[k]));
-        b->chain_pending = false;
-    }
-    HIP_TRY(drain_stream(b->stream));
+    b->chain_pending = false;
+    if (!drained) HIP_TRY(drain_stream(b->stream));
     b->home_async = false;
     b->busy = false;
     b->gate_count = 0; b->gate_pending[0] = b->gate_pending[1] = 0;
@@ -1035,7 +1036,7 @@ static int create_impl(tetris_batch** out, int n_games, int n_players, int heigh
     CREATE_TRY(hipEventCreate(&b->ev0));
     CREATE_TRY(hipEventCreate(&b->ev1));
     for (int k = 0; k < CHAIN_STREAMS; k++) CREATE_TRY(hipStreamCreateWithFlags(&b->chain_stream[k], hipStreamNonBlocking));
-    for (int k = 0; k < 3; k++) CREATE_TRY(hipEventCreateWithFlags(&b->chain_ev[k], hipEventDisableTiming));
+    for (int k = 0; k < CHAIN_STREAMS + 1; k++) CREATE_TRY(hipEventCreateWithFlags(&b->chain_ev[k], hipEventDisableTiming));
     {
         const size_t chain_bytes = (((size_t)n_games + 15) / 16) * sizeof(uint32_t) * CHAIN_STRIDE;       // (one word per wave; at least 16 games per wave)
         CREATE_TRY(hipMalloc((void**)&b->d_chain, chain_bytes));
@@ -1786,8 +1787,8 @@ int tetris_rollout_launch(tetris_batch* b, int launches, int steps_per_launch, u
     if (chained && b->home_async) {
         // both chain streams start behind the asynchronous work the batch's stream still holds (after a synchronous call it
         // is empty and nothing has to be ordered)
-        HIP_TRY(hipEventRecord(b->chain_ev[2], home));
-        for (int k = 0; k < CHAIN_STREAMS; k++) HIP_TRY(hipStreamWaitEvent(b->chain_stream[k], b->chain_ev[2], 0));
+        HIP_TRY(hipEventRecord(b->chain_ev[CHAIN_STREAMS], home));
+        for (int k = 0; k < CHAIN_STREAMS; k++) HIP_TRY(hipStreamWaitEvent(b->chain_stream[k], b->chain_ev[CHAIN_STREAMS], 0));
     }
     // Measurement aid (TETRIS_PREQUEUE=1, read per call; bench.py's `launch_us_gpu_paced`): the chain streams are parked behind a
     // ~5 ms blocker kernel while the host enqueues, so every launch of the call is queued before the first one starts and the
@@ -1795,8 +1796,8 @@ int tetris_rollout_launch(tetris_batch* b, int launches, int steps_per_launch, u
     const bool prequeue = getenv("TETRIS_PREQUEUE") != nullptr;
     if (chained && prequeue && launches <= 600) {
         hipLaunchKernelGGL(k_blocker, dim3(1), dim3(64), 0, home, 200000);           // ~5 ms
-        HIP_TRY(hipEventRecord(b->chain_ev[2], home));
-        for (int k = 0; k < CHAIN_STREAMS; k++) HIP_TRY(hipStreamWaitEvent(b->chain_stream[k], b->chain_ev[2], 0));
+        HIP_TRY(hipEventRecord(b->chain_ev[CHAIN_STREAMS], home));
+        for (int k = 0; k < CHAIN_STREAMS; k++) HIP_TRY(hipStreamWaitEvent(b->chain_stream[k], b->chain_ev[CHAIN_STREAMS], 0));
         group = 1 << 20;
     }
     HIP_TRY(hipEventRecord(b->ev0, chained ? b->chain_stream[0] : home));
@@ -1823,18 +1824,38 @@ int tetris_rollout_launch(tetris_batch* b, int launches, int steps_per_launch, u
         } else if ((rc = launch_game<M_ROLLOUT>(b, a)))
             return rc;
     }
-    // the last launch ends after every wave of the launch before it has published its epoch: its stream carries the end event
-    HIP_TRY(hipEventRecord(b->ev1, b->stream));
+    // Every chain stream gets an event behind its last launch (the last launch's stream carries the timing event ev1); the host
+    // waits for these events by polling them — an interrupt wakes a blocked thread 10-20 us late, and querying a STREAM makes the
+    // runtime push a marker through its queue and wait for it, ~6 us per stream even when it is idle.  Nothing on the GPU waits
+    // for another stream here (a cross-stream join costs the rollout ~15 us at its end); the batch's own stream is ordered behind
+    // the events for whatever comes next.
+    hipStream_t const last = b->stream;
+    const int used = chained ? (launches < CHAIN_STREAMS ? launches : CHAIN_STREAMS) : 0;
+    HIP_TRY(hipEventRecord(b->ev1, last));
+    for (int k = 0; k < used; k++)
+        if (b->chain_stream[k] != last) HIP_TRY(hipEventRecord(b->chain_ev[k], b->chain_stream[k]));
+    for (int k = 0; k < used; k++) HIP_TRY(hipStreamWaitEvent(home, b->chain_stream[k] != last ? b->chain_ev[k] : b->ev1, 0));
     b->stream = home;
     const auto t_enq = std::chrono::steady_clock::now();
-    if ((rc = finish_call(b))) return rc;         // drains both chain streams and the batch's own
+    {
+        auto poll = [](hipEvent_t e) {
+            hipError_t qe = hipErrorNotReady;
+            for (int spin = 0; spin < 200000 && qe == hipErrorNotReady; spin++) qe = hipEventQuery(e);
+            return qe == hipErrorNotReady ? hipEventSynchronize(e) : qe;
+        };
+        HIP_TRY(poll(b->ev1));
+        for (int k = 0; k < used; k++)
+            if (b->chain_stream[k] != last) HIP_TRY(poll(b->chain_ev[k]));
+    }
+    const double ev1_us = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count() * 1e6;
+    if ((rc = finish_call(b, true))) return rc;   // the end event is behind everything this call enqueued: no stream drains
     if (elapsed_ms) HIP_TRY(hipEventElapsedTime(elapsed_ms, b->ev0, b->ev1));
     if (timing) {
         const double enq = std::chrono::duration<double>(t_enq - t_begin).count(), all = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
         fprintf(stderr, "[tetris timing] %d launches: host enqueue %.2f us/launch (of which gate + flags %.2f), until drained %.2f us/launch; "
-                "call entry -> first enqueue %.1f us, whole call %.1f us, between the events %.1f us\n",
+                "call entry -> first enqueue %.1f us, end event seen %.1f us after the first enqueue, whole call %.1f us, between the events %.1f us\n",
                 launches, enq * 1e6 / launches, gate_s * 1e6 / launches, all * 1e6 / launches,
-                std::chrono::duration<double>(t_begin - t_entry).count() * 1e6, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_entry).count() * 1e6,
+                std::chrono::duration<double>(t_begin - t_entry).count() * 1e6, ev1_us, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_entry).count() * 1e6,
                 elapsed_ms ? *elapsed_ms * 1e3 : 0.0);
     }
     return TETRIS_OK;
