@@ -235,7 +235,7 @@ def main():
         launch_us_events = ev_ms * 1e3 / args.steps if ev_ms > 0 else None     # (the CPU rehearsal library has no events)
         lib_path = os.path.abspath(os.environ.get("BENCH_LIB_PATH") or ge.LIB)
         roofline = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "kernel": "k_chain<1> (chained launches: two streams, each wave waits for its own predecessor's epoch word)" if chained
+                    "kernel": "k_chain<1> (chained launches: three streams, each wave waits for its own predecessor's epoch word)" if chained
                               else ("k_duo<M_ROLLOUT>" if (P == 2 and S == 1) else f"k_game<{P}, M_ROLLOUT>"),
                     "launch_us": launch_us, "launch_us_events": launch_us_events, "clock": "wall (same clock as `value`)"}
         if chained:
