@@ -115,7 +115,7 @@ def test_batch_independence_and_order_invariance():
 
 
 def test_chained_launches_bit_exact_and_only_where_the_launches_in_flight_fit():
-    """Chained rollout launches (tetris_set_chained: two streams, per-wave epoch words) against the oracle, switching the mode
+    """Chained rollout launches (tetris_set_chained: three streams, per-wave epoch words) against the oracle, switching the mode
     back and forth in one batch; the library chains only where the launches in flight (three) fit on the device together."""
     n = 65536
     seeds = orc.episode_seed(np.arange(n), 0)
