@@ -1745,7 +1745,7 @@ int tetris_rollout_launch(tetris_batch* b, int launches, int steps_per_launch, u
     // Only when CHAIN_STREAMS launches fit on the device together (chain_fits): a waiting wave keeps its slot, so a launch whose waves
     // wait must never be able to keep its predecessor's waves from being dispatched.
     const bool chained = rollout_chained(b, steps_per_launch) && chain_acquire(b);
-    struct ChainGuard {                           // (released on every return path; the call ends with both chain streams drained)
+    struct ChainGuard {                           // (released on every return path; the call ends with every chain stream idle)
         tetris_batch* b; bool held;
         ~ChainGuard() { if (held) chain_release(b); }
     } chain_guard{b, chained};
@@ -1785,7 +1785,7 @@ int tetris_rollout_launch(tetris_batch* b, int launches, int steps_per_launch, u
         return TETRIS_OK;
     }
     if (chained && b->home_async) {
-        // both chain streams start behind the asynchronous work the batch's stream still holds (after a synchronous call it
+        // the chain streams start behind the asynchronous work the batch's stream still holds (after a synchronous call it
         // is empty and nothing has to be ordered)
         HIP_TRY(hipEventRecord(b->chain_ev[CHAIN_STREAMS], home));
         for (int k = 0; k < CHAIN_STREAMS; k++) HIP_TRY(hipStreamWaitEvent(b->chain_stream[k], b->chain_ev[CHAIN_STREAMS], 0));

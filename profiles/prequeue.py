@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""GPU-paced period of chained launches: TETRIS_PREQUEUE=1 parks both chain streams behind a ~5 ms blocker kernel, so all 512
+"""GPU-paced period of chained launches: TETRIS_PREQUEUE=1 parks the chain streams behind a ~5 ms blocker kernel, so all 512
 launches of a call are queued before the first starts — the host's launch cost (2.5-5 us per launch, varies between processes
 and boxes) does not enter.  argv: P [library build, default = in-tree].  Prints pre-queued (HIP events) and host-paced periods."""
 import os

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Soak of the chained rollout launches: 65 536 single-player boards x N single-step launches (default 10 000 = 6.6e8 env-steps,
-~3e7 episodes) on two alternating streams with per-wave epoch hand-over, then counters and EVERY board's complete state against
+~3e7 episodes) on the rotating chain streams with per-wave epoch hand-over, then counters and EVERY board's complete state against
 the oracle on all host cores.  A stale read anywhere in the hand-over would show up here as a diverging board."""
 import os
 import sys
