@@ -234,6 +234,8 @@ int tetris_rollout_launch(tetris_batch *b, int launches, int steps_per_launch, u
  * The fit is computed for a device this process has to itself: kernels of OTHER processes that occupy wave slots of the same
  * GPU can keep a launch from fitting beside its successor; the waiting waves then give up after their bound and the call
  * fails as above (nothing hangs) — share a GPU between processes with chaining off.
+ * The three streams overlap only on different hardware queues: the HIP runtime gives a process four (GPU_MAX_HW_QUEUES) and
+ * deals its streams onto them in turn, so a process that keeps many other streams busy should raise that number.
  * on = 0: every launch on the batch's one stream.  (Environment: TETRIS_NO_CHAIN=1 sets the default to off.)           */
 int tetris_set_chained(tetris_batch *b, int on);
 /* Environment variables read by the library (measurement aids; none changes a result):
