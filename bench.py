@@ -24,11 +24,6 @@ import os
 import sys
 import time
 
-# The chained launches rotate over three HIP streams, which must sit on three different hardware queues to overlap (with
-# GPU_MAX_HW_QUEUES=2 the same run takes 5.1 us per launch instead of 4.0: profiles/r02/hw_queues.txt).  The runtime's default of
-# four queues per process is enough for this script; eight leaves room for whatever else the process creates.  Must be set
-# before the HIP runtime initialises.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np
 

@@ -1035,7 +1035,19 @@ static int create_impl(tetris_batch** out, int n_games, int n_players, int heigh
     b->own_stream = b->stream;
     CREATE_TRY(hipEventCreate(&b->ev0));
     CREATE_TRY(hipEventCreate(&b->ev1));
-    for (int k = 0; k < CHAIN_STREAMS; k++) CREATE_TRY(hipStreamCreateWithFlags(&b->chain_stream[k], hipStreamNonBlocking));
+    {
+        // Every chain stream gets a stream priority of its own.  Not for the priorities' sake: the runtime keeps one hardware queue per
+        // priority level apart from the four (GPU_MAX_HW_QUEUES) it deals ordinary streams onto in turn, and two chain streams on ONE
+        // hardware queue do not overlap (measured with GPU_MAX_HW_QUEUES=2: 5.07 us per launch with equal priorities, 3.99 with three
+        // different ones; with four queues 4.00 either way: profiles/r02/hw_queues.txt).  TETRIS_CHAIN_PRIO=0: equal priorities.
+        int lo = 0, hi = 0;
+        const char* e = getenv("TETRIS_CHAIN_PRIO");
+        const bool spread = !(e && e[0] == '0') && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo - hi + 1 >= CHAIN_STREAMS;
+        for (int k = 0; k < CHAIN_STREAMS; k++) {
+            if (spread) CREATE_TRY(hipStreamCreateWithPriority(&b->chain_stream[k], hipStreamNonBlocking, hi + k));
+            else CREATE_TRY(hipStreamCreateWithFlags(&b->chain_stream[k], hipStreamNonBlocking));
+        }
+    }
     for (int k = 0; k < CHAIN_STREAMS + 1; k++) CREATE_TRY(hipEventCreateWithFlags(&b->chain_ev[k], hipEventDisableTiming));
     {
         const size_t chain_bytes = (((size_t)n_games + 15) / 16) * sizeof(uint32_t) * CHAIN_STRIDE;       // (one word per wave; at least 16 games per wave)

@@ -234,8 +234,8 @@ int tetris_rollout_launch(tetris_batch *b, int launches, int steps_per_launch, u
  * The fit is computed for a device this process has to itself: kernels of OTHER processes that occupy wave slots of the same
  * GPU can keep a launch from fitting beside its successor; the waiting waves then give up after their bound and the call
  * fails as above (nothing hangs) — share a GPU between processes with chaining off.
- * The three streams overlap only on different hardware queues: the HIP runtime gives a process four (GPU_MAX_HW_QUEUES) and
- * deals its streams onto them in turn, so a process that keeps many other streams busy should raise that number.
+ * The three streams overlap only on different hardware queues; they are created with three different stream priorities, which
+ * the HIP runtime keeps on separate hardware queues whatever else the process has running (TETRIS_CHAIN_PRIO=0: equal ones).
  * on = 0: every launch on the batch's one stream.  (Environment: TETRIS_NO_CHAIN=1 sets the default to off.)           */
 int tetris_set_chained(tetris_batch *b, int on);
 /* Environment variables read by the library (measurement aids; none changes a result):
@@ -245,6 +245,7 @@ int tetris_set_chained(tetris_batch *b, int on);
  *                       launch costs the host more than the kernel takes; from a graph the profiled kernels are back to back)
  *   TETRIS_PREQUEUE=1   (read per call) tetris_rollout_launch of <= 600 chained launches parks its streams behind a ~5 ms blocker
  *                       kernel until every launch is queued: the GPU-paced launch period, without the host's launch cost
+ *   TETRIS_CHAIN_PRIO=0 the chain streams are created with equal priorities (they may then share a hardware queue)
  *   TETRIS_TIMING=1     tetris_rollout_launch prints its host-side costs (enqueue per launch, gate waits, until drained) to stderr */
 /* 1 if tetris_rollout_launch / tetris_rollout_random would chain launches of `steps_per_launch` steps on this batch, 0 if not
  * (switched off, caller-owned stream, split or colour batch, or three launches do not fit on the device together: a waiting
