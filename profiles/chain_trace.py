@@ -30,6 +30,7 @@ PH = {4: "philox+prefetch issued", 10: "kt: shapes+band+no-kick tests", 11: "kt:
       6: "settle (clear/spawn) done", 7: "tick done", 8: "auto-reset done"}
 PH_ORDER = [4, 10, 11, 12, 13, 5, 6, 7, 8]
 buf = np.zeros(8 * 1024 * 8, np.uint64)
+STREAMS = 3          # chain streams the library rotates over (CHAIN_STREAMS): launch E follows launch E - STREAMS on its stream
 NAMES = ["entry", "policy drawn", "epoch seen", "state arrived", "stores issued", "stores acked", "published"]
 b.rollout_random(200, 1)
 assert b.rollout_is_chained(1)
@@ -59,8 +60,8 @@ for rep in range(3):
     print(f"  hand-off: published by E-1 -> epoch seen by E: median {gap.mean():.2f} mean, {np.median(gap):.2f} median, p90 {np.percentile(gap, 90):.2f}")
     early = (t[2:6, :, 6] - t[3:7, :, 1]).ravel()
     print(f"  successor already waiting when E-1 publishes (published E-1 minus 'policy drawn' of E): median {np.median(early):.2f}  p10 {np.percentile(early, 10):.2f}  frac>0 {np.mean(early > 0):.2f}")
-    for k in range(2, 6):
-        first_in, last_pub = t[k + 2, :, 0].min(), t[k, :, 6].max()
+    for k in range(1, 8 - STREAMS):
+        first_in, last_pub = t[k + STREAMS, :, 0].min(), t[k, :, 6].max()
         med_pub = np.median(t[k, :, 6])
         w = int(np.argmax(t[k, :, 6]))
         ph = " ".join(f"{t[k, w, j + 1] - t[k, w, j]:.2f}" for j in range(6))
@@ -73,7 +74,7 @@ for rep in range(3):
         comp = t[k, :, 4] - t[k, :, 3]
         print(f"  launch {k}: {len(keys)} SIMDs used by 1024 waves; waves per SIMD histogram {np.bincount(counts).tolist()}; "
               + "; ".join(f"compute median with {c} on the SIMD: {np.median(comp[share == c]):.2f} us (n={int((share == c).sum())})" for c in sorted(set(share.tolist()))))
-        print(f"     distinct XCDs {len(set(xcc[k].tolist()))}, CUs {len(set((simd_key[k] // 4).tolist()))}; same wave on the same SIMD as in the launch before: {np.mean(simd_key[k] == simd_key[k - 1]):.2f}, same XCD: {np.mean(xcc[k] == xcc[k - 1]):.2f}, same XCD as two launches before: {np.mean(xcc[k] == xcc[k - 2]):.2f}")
+        print(f"     distinct XCDs {len(set(xcc[k].tolist()))}, CUs {len(set((simd_key[k] // 4).tolist()))}; same wave on the same SIMD as in the launch before: {np.mean(simd_key[k] == simd_key[k - 1]):.2f}, same XCD: {np.mean(xcc[k] == xcc[k - 1]):.2f}, same XCD as {STREAMS} launches before: {np.mean(xcc[k] == xcc[k - STREAMS]):.2f}")
     # inside the step of the LAST launch (shader-clock stamps of game_run, ~2.47 cycles per ns)
     assert lib.tetris_debug_trace(buf2.ctypes.data, buf2.size) == 0
     c = buf2.reshape(2048, 16)[:1024].astype(np.int64)
