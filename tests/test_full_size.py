@@ -146,3 +146,19 @@ def test_chained_launches_bit_exact_and_only_where_the_launches_in_flight_fit():
     _, want = sref.rollout_random(200, threads=8)
     assert (c1 + c2).tolist() == want.tolist()
     engines.assert_same_state(small, sref, where="two-player, chained then not")
+
+
+@pytest.mark.parametrize("P", [1, 2])
+def test_chained_launches_at_batch_sizes_that_are_not_whole_waves(P):
+    """Chained launches (three streams, one epoch word per wave) on batches whose last wave is partly empty, and on batches
+    smaller than a wave: counters and every board against the oracle, single steps and fused ones."""
+    for n in (1, 63, 65, 1000, 5001):
+        seeds = orc.episode_seed(np.arange(n), 0)
+        eng, ref = engines.make("hip", n, P, seeds=seeds), engines.make("oracle", n, P, seeds=seeds)
+        assert eng.rollout_is_chained(1)
+        c1, _ = eng.rollout_random(150, 1)
+        c2, _ = (eng.rollout_random(5, 10, first_step=150) if P == 1 else eng.rollout_random(50, 1, first_step=150))
+        _, want = ref.rollout_random(200, threads=8)
+        assert (c1 + c2).tolist() == want.tolist(), n
+        engines.assert_same_state(eng, ref, where=f"n={n}")
+        eng.close()
