@@ -251,7 +251,8 @@ def main():
             if gpu_paced_us:
                 roofline.update({"launch_us_gpu_paced": gpu_paced_us, "frac_gpu_paced": algo_bytes / (gpu_paced_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                                  "gpu_paced_note": "extra run AFTER the timed region: 512 launches queued behind a blocker kernel before the first starts "
-                                                   "(HIP events); `value`, `launch_us` and `frac` above are the host-paced wall clock of the K timed launches"})
+                                                   "(HIP events); `value`, `launch_us` and `frac` above are the host-paced wall clock of the K timed launches "
+                                                   "(on a host that launches faster than the GPU steps the two agree to a few per cent; a slower host shows in the wall clock only)"})
             # HBM traffic cannot be measured inside this process: it comes from separate rocprofv3 --pmc passes over this same
             # command (profiles/pmc_passes.sh), corrected as MI355X_MICROARCH.md prescribes; the file is named next to the number
             pmc = os.path.join(ROOT, "profiles", "r02", f"pmc_p{P}_s{S}.json")
