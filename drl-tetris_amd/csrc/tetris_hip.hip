@@ -747,6 +747,7 @@ struct tetris_batch {
     int use_chain = 1;                   // TETRIS_NO_CHAIN=1 in the environment: every rollout launch on the batch's one stream
     int use_graph = 0;                   // TETRIS_GRAPH=1: un-chained rollout launches replayed from HIP graphs (profiling aid)
     long long chain_capacity = -1;       // wave slots of the device for the chained kernel (computed on first use)
+    int chain_depth = 0;                 // launches in flight = streams rotated over (3, or 2 where only two launches fit; 0: not chained)
     bool chain_pending = false;          // chained launches were enqueued since the last drain
     bool home_async = false;             // asynchronous (_dev) work was enqueued on the batch's stream since the last drain
     bool busy = true;                    // something was enqueued on one of the batch's streams since the last drain
@@ -805,21 +806,30 @@ static int launch_game(tetris_batch* b, const KArgs& a) {
 
 // Chained launches are deadlock-free only if the waves of all launches in flight can be resident together: the waves of
 // launch E spin (in their slots) until the same waves of launch E - 1 have published, so E - 1 must never be short of a slot
-// because of them.  At most CHAIN_STREAMS launches are in flight (E follows E - CHAIN_STREAMS on its stream, so the oldest
-// launch in flight never waits for an epoch: its predecessor has completed).  The occupancy API can be
+// because of them.  At most `chain_depth` launches are in flight — the streams rotated over: CHAIN_STREAMS (3), or 2 where only two
+// launches fit (E follows E - depth on its stream, so the oldest launch in flight never waits for an epoch: its predecessor has
+// completed).  The occupancy API can be
 // one workgroup per CU too high for kernels of this SGPR count (MI355X_MICROARCH.md, correctness boundaries): one is
 // subtracted.  64k single-player boards: 1 024 waves per launch, 15 x 256 slots.  64k two-player boards (k_duo, 220
 // VGPRs: 8 waves per CU): 2 048 waves per launch, 7 x 256 slots — does not fit, those launches stay on one stream.
+static const void* chain_kernel(tetris_batch* b, long long* waves) {
+    if (b->P == 1) { *waves = ((long long)b->N + CHAIN_LANES - 1) / CHAIN_LANES; return (const void*)k_chain<1>; }
+    *waves = ((long long)b->N + 31) / 32;
+    return (const void*)k_duo<M_ROLLOUT, true>;
+}
 static bool chain_fits(tetris_batch* b) {
+    long long waves = 0;
+    const void* fn = chain_kernel(b, &waves);
     if (b->chain_capacity < 0) {
         int per_cu = 0, cus = 0;
-        const void* fn = b->P == 1 ? (const void*)k_chain<1> : (const void*)k_duo<M_ROLLOUT, true>;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64, 0) != hipSuccess) per_cu = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b->device) != hipSuccess) cus = 0;
         b->chain_capacity = per_cu > 1 ? (long long)(per_cu - 1) * cus : 0;
     }
-    const long long waves = b->P == 1 ? ((long long)b->N + CHAIN_LANES - 1) / CHAIN_LANES : ((long long)b->N + 31) / 32;
-    return CHAIN_STREAMS * waves <= b->chain_capacity;
+    b->chain_depth = 0;
+    for (int d = CHAIN_STREAMS; d >= 2 && !b->chain_depth; d--)
+        if (d * waves <= b->chain_capacity) b->chain_depth = d;
+    return b->chain_depth >= 2;
 }
 
 // Looks at the flag words WITHOUT enqueuing or waiting for anything: answers a pending "extend the RNG tables" request
@@ -1821,7 +1831,7 @@ int tetris_rollout_launch(tetris_batch* b, int launches, int steps_per_launch, u
     const auto t_begin = std::chrono::steady_clock::now();
     double gate_s = 0.0;
     for (int l = 0; l < launches; l++) {
-        if (chained) { b->stream = b->chain_stream[l % CHAIN_STREAMS]; b->chain_pending = true; }
+        if (chained) { b->stream = b->chain_stream[l % b->chain_depth]; b->chain_pending = true; }
         const auto t_gate = std::chrono::steady_clock::now();
         if ((rc = gate_launch(b, group))) return rc;
         if (timing) gate_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_gate).count();
@@ -1842,7 +1852,7 @@ int tetris_rollout_launch(tetris_batch* b, int launches, int steps_per_launch, u
     // for another stream here (a cross-stream join costs the rollout ~15 us at its end); the batch's own stream is ordered behind
     // the events for whatever comes next.
     hipStream_t const last = b->stream;
-    const int used = chained ? (launches < CHAIN_STREAMS ? launches : CHAIN_STREAMS) : 0;
+    const int used = chained ? (launches < b->chain_depth ? launches : b->chain_depth) : 0;
     HIP_TRY(hipEventRecord(b->ev1, last));
     for (int k = 0; k < used; k++)
         if (b->chain_stream[k] != last) HIP_TRY(hipEventRecord(b->chain_ev[k], b->chain_stream[k]));
