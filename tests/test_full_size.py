@@ -162,3 +162,19 @@ def test_chained_launches_at_batch_sizes_that_are_not_whole_waves(P):
         assert (c1 + c2).tolist() == want.tolist(), n
         engines.assert_same_state(eng, ref, where=f"n={n}")
         eng.close()
+
+
+def test_chain_depth_two_where_three_launches_do_not_fit():
+    """98 304 single-player boards = 1 536 waves per launch: three launches (4 608 waves) do not fit in the device's wave slots, two
+    do — the library then rotates over two streams instead of three (or not chaining at all).  Counters and every board against the
+    oracle."""
+    n = 98304
+    seeds = orc.episode_seed(np.arange(n), 0)
+    eng, ref = engines.make("hip", n, 1, seeds=seeds), engines.make("oracle", n, 1, seeds=seeds)
+    assert eng.rollout_is_chained(1)
+    c1, _ = eng.rollout_random(70, 1)
+    c2, _ = eng.rollout_random(3, 10, first_step=70)
+    _, want = ref.rollout_random(100, threads=min(32, len(os.sched_getaffinity(0))))
+    assert (c1 + c2).tolist() == want.tolist()
+    for lo in range(0, n, 8192):
+        engines.assert_same_state(eng, ref, idx=np.arange(lo, lo + 8192, dtype=np.int32), where=f"games {lo}..")
