@@ -229,7 +229,8 @@ int tetris_rollout_launch(tetris_batch *b, int launches, int steps_per_launch, u
  * and are ordered per WAVE — the 64 games of a wave wait, inside the kernel, for an epoch word that the same wave
  * of the previous launch publishes after its state stores have drained — instead of per launch by the stream (where every
  * launch waits for the slowest wave of the whole previous launch plus the kernel boundary).  Results are bit-identical.
- * A wave that waits keeps its slot; launches are therefore chained only while three of them fit on the device together, and a
+ * A wave that waits keeps its slot; launches are therefore chained only while three of them — for larger batches two, over
+ * two streams — fit on the device together, and a
  * wave never waits unboundedly (after ~3 s it gives up, the call fails with TETRIS_E_HIP and the state is invalid).
  * The fit is computed for a device this process has to itself: kernels of OTHER processes that occupy wave slots of the same
  * GPU can keep a launch from fitting beside its successor; the waiting waves then give up after their bound and the call
@@ -248,7 +249,7 @@ int tetris_set_chained(tetris_batch *b, int on);
  *   TETRIS_CHAIN_PRIO=0 the chain streams are created with equal priorities (they may then share a hardware queue)
  *   TETRIS_TIMING=1     tetris_rollout_launch prints its host-side costs (enqueue per launch, gate waits, until drained) to stderr */
 /* 1 if tetris_rollout_launch / tetris_rollout_random would chain launches of `steps_per_launch` steps on this batch, 0 if not
- * (switched off, caller-owned stream, split or colour batch, or three launches do not fit on the device together: a waiting
+ * (switched off, caller-owned stream, split or colour batch, or not even two launches fit on the device together: a waiting
  * wave keeps its slot, so chaining is only used where it cannot keep the launch it waits for from being dispatched —
  * 64k single-player boards fit, 64k two-player boards do not).                                                          */
 int tetris_rollout_is_chained(tetris_batch *b, int steps_per_launch);
