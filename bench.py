@@ -6,8 +6,11 @@
 One "step" = one launch of the rollout kernel = ONE env-step on every game of the batch (state is
 read from HBM, stepped, auto-reset where done, written back).  N=1 workload = BASELINE.json
 configs[1]: 65 536 parallel 20x10 single-player boards, random (rotation, translation) policy.
-For N>1 (launched by torch.distributed.run, one rank per GPU) every rank owns its own 65 536 games:
-games never interact across ranks, so there is no data-path collective ("scaling": "weak").
+For N>1 every rank (one process per GPU) owns its own 65 536 games: games never interact across ranks, so there is no
+data-path collective ("scaling": "weak").  `python bench.py --gpus N` starts its own N ranks (a parent that touches no GPU
+spawns one child per device and relays rank 0's line; fewer than N visible devices, or a rank that fails, is a non-zero
+exit — never a silent run on fewer GPUs); under an external launcher (torch.distributed.run: RANK / WORLD_SIZE in the
+environment) it is one of the launcher's ranks, and WORLD_SIZE must equal --gpus.
 
 Prints ONE JSON line (rank 0).  `value` = env-steps of all ranks / max-over-ranks wall time of the
 K timed launches, inputs resident in HBM; nothing but the K step-kernel launches lies inside that
@@ -106,13 +109,14 @@ def bench_split(args, mod, dist, rank, world, local_rank):
                             device=local_rank, lib_path=os.environ.get("BENCH_LIB_PATH"))
     so.batch.set_game_offset(pair * N)
     so.rollout(args.warmup)
+    before = [int(x) for x in so.batch.rollout_totals()]
     dist.barrier()
     wall = so.rollout(args.steps, first_step=args.warmup)
     dist.barrier()
     dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
     t = torch.tensor([wall], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    tot = torch.tensor([int(x) for x in so.batch.rollout_totals()], dtype=torch.int64, device=dev)
+    tot = torch.tensor([int(x) - b for x, b in zip(so.batch.rollout_totals(), before)], dtype=torch.int64, device=dev)      # the timed steps only
     if rank % 2:
         tot[0] = 0                                   # env-steps and episodes are counted once per game (by side 0)
         tot[1] = 0
@@ -129,7 +133,7 @@ def bench_split(args, mod, dist, rank, world, local_rank):
             "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": {"workload": f"{N} two-player {args.height}x10 games per GPU pair, player 0 and player 1 on different GPUs, "
                                    "random policy, auto-reset, garbage exchange = 3 all-gathers of 4 B per board per step",
-                       "games_per_pair": N, "players": 2, "parallelism": f"{world // 2} pairs, all-gather over {world} ranks"},
+                       "games_per_pair": N, "players": 2, "parallelism": f"{world // 2} pair(s) of GPUs, every exchange an all-gather inside the pair's own process group (2 ranks)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "kernel": "k_split<0..2> + 3 all-gathers per step (wall time, not kernel time)",
                          "algorithmic_bytes_per_launch": algo, "launch_us": per_step_us},
@@ -137,6 +141,70 @@ def bench_split(args, mod, dist, rank, world, local_rank):
             "cpu_baseline": None}))
     so.close()
     dist.destroy_process_group()
+
+
+def visible_devices():
+    """GPUs this process may use, WITHOUT initialising the HIP runtime (the parent of the ranks must stay free of it: a
+    process that has touched the GPU must not start other programs on this pool): torch.cuda.device_count() reads the
+    driver's device list only."""
+    import torch
+    return int(torch.cuda.device_count())
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: N child processes, one per device, rendezvous on 127.0.0.1; rank 0's
+    stdout (the JSON line) is relayed, every rank's stderr passes through.  Returns the exit code."""
+    import socket
+    import subprocess
+    n = args.gpus
+    rehearsal = os.environ.get("BENCH_LIB_PATH") is not None          # CPU rehearsal (tests): no devices to count
+    if not rehearsal:
+        have = visible_devices()
+        if have < n:
+            print(f"bench.py: --gpus {n} but only {have} GPU(s) visible to this process; refusing to run on fewer", file=sys.stderr)
+            return 2
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    deadline = time.time() + float(os.environ.get("BENCH_SPAWN_TIMEOUT_S", "1500"))
+    rc, pending = 0, set(range(n))
+    while pending and not rc:
+        for r in sorted(pending):
+            code = procs[r].poll()
+            if code is not None:
+                pending.discard(r)
+                if code != 0:
+                    print(f"bench.py: rank {r} exited with code {code}", file=sys.stderr)
+                    rc = code if code > 0 else 1
+        if time.time() > deadline:
+            print("bench.py: ranks did not finish in time", file=sys.stderr)
+            rc = 3
+        if pending and not rc:
+            time.sleep(0.05)
+    for r in pending:                                  # a rank failed (or the deadline passed): end the others — these exact processes
+        procs[r].kill()
+    out = procs[0].stdout.read() if procs[0].stdout else ""
+    for pr in procs:
+        pr.wait()
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    if not rc and len(lines) != 1:
+        print(f"bench.py: expected one JSON line from rank 0, got {len(lines)}", file=sys.stderr)
+        rc = 4
+    if not rc:
+        line = json.loads(lines[0])
+        if line.get("n_gpus") != n:
+            print(f"bench.py: rank 0 reports n_gpus {line.get('n_gpus')} for --gpus {n}", file=sys.stderr)
+            rc = 5
+        else:
+            print(lines[0])
+    return rc
 
 
 def main():
@@ -155,8 +223,18 @@ def main():
     ap.add_argument("--workload", choices=["sharded", "split"], default="sharded",
                     help="sharded (default): every rank owns whole games, no collective.  split: BASELINE config 5 — ranks 2k and 2k+1 "
                          "hold player 0 / player 1 of the same games, garbage exchange by three RCCL all-gathers per step (even N only)")
+    ap.add_argument("--no-gpu-paced", action="store_true", help="skip the extra GPU-paced run after the timed region (profiling runs)")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            sys.exit(spawn_ranks(args))                # parent: no GPU call, no HIP library in this process
+    elif int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        # under a launcher: its world IS the job.  A mismatch would print a line about a different job than the one asked for.
+        print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={os.environ.get('WORLD_SIZE', '1')} rank(s)", file=sys.stderr)
+        sys.exit(2)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -166,16 +244,16 @@ def main():
         import torch.distributed as dist
 
         backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")     # "gloo" only to rehearse N>1 on a 1-GPU box
-        local_rank = local_rank % max(1, torch.cuda.device_count())
+        if backend == "nccl" and int(os.environ.get("LOCAL_WORLD_SIZE", world)) > torch.cuda.device_count():
+            print(f"bench.py: {os.environ.get('LOCAL_WORLD_SIZE', world)} ranks on this node but {torch.cuda.device_count()} GPU(s) visible", file=sys.stderr)
+            sys.exit(2)
+        local_rank = local_rank % max(1, torch.cuda.device_count())      # (wraps only in the gloo rehearsal of N ranks on fewer devices)
         if torch.cuda.is_available():                              # (absent only in the CPU rehearsal with gloo + BENCH_LIB_PATH)
             torch.cuda.set_device(local_rank)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
-
     ge.package()
     import importlib
     sharded = importlib.import_module("drl-tetris_amd.distributed")
@@ -211,7 +289,7 @@ def main():
     # cost (2.5-5 us per launch, it varies between processes and boxes and sets the pace where it exceeds the GPU's period)
     # does not enter.  Reported beside the wall-clock figures, never as `value`.
     gpu_paced_us = None
-    if world == 1 and S == 1 and shard.batch.rollout_is_chained(S) and os.environ.get("BENCH_LIB_PATH") is None:
+    if world == 1 and S == 1 and not args.no_gpu_paced and shard.batch.rollout_is_chained(S) and os.environ.get("BENCH_LIB_PATH") is None:
         os.environ["TETRIS_PREQUEUE"] = "1"
         try:
             shard.run(64, S)
@@ -255,12 +333,14 @@ def main():
                                                    "(on a host that launches faster than the GPU steps the two agree to a few per cent; a slower host shows in the wall clock only)"})
             # HBM traffic cannot be measured inside this process: it comes from separate rocprofv3 --pmc passes over this same
             # command (profiles/pmc_passes.sh), corrected as MI355X_MICROARCH.md prescribes; the file is named next to the number
-            pmc = os.path.join(ROOT, "profiles", "r02", f"pmc_p{P}_s{S}.json")
+            pmc = os.path.join(ROOT, "profiles", "r03", f"pmc_p{P}_s{S}.json")
             traffic, source = None, None
             if os.path.exists(pmc):
                 try:
                     traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-                    source = os.path.relpath(pmc, ROOT) + " (separate rocprofv3 --pmc passes of this command: FETCH_SIZE x 2 + WRITE_SIZE per launch)"
+                    source = (os.path.relpath(pmc, ROOT) + " (separate rocprofv3 --pmc passes of this command with the dispatches serialised, "
+                              "TETRIS_CHAIN_DEPTH=1: raw TCC_EA0 request counters -> bytes, reads x the factor calibrated on zero-step launches; "
+                              "fabric side of the L2, Infinity-Cache hits included)")
                 except Exception:
                     traffic = None
             roofline.update({"traffic": traffic, "traffic_source": source})

@@ -57,6 +57,8 @@ _SIGNATURES = {
     "tetris_set_game_offset": (C.c_int, [C.c_void_p, C.c_uint64]),
     "tetris_set_chained": (C.c_int, [C.c_void_p, C.c_int]),
     "tetris_rollout_is_chained": (C.c_int, [C.c_void_p, C.c_int]),
+    "tetris_set_chain_spin_limit": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "tetris_debug_stall": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "tetris_reset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "tetris_make_actions": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
     "tetris_finish_actions": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -370,6 +372,15 @@ class TetrisBatch:
         """Chained launches of the built-in rollout on / off (include/tetris_hip.h: tetris_set_chained)."""
         self._check(self.lib.tetris_set_chained(self._h, 1 if on else 0))
 
+    def set_chain_spin_limit(self, polls):
+        """Polls of the predecessor's epoch word after which a waiting wave of a chained launch gives up (0 = default, ~2 s)."""
+        self._check(self.lib.tetris_set_chain_spin_limit(self._h, int(polls)))
+
+    def debug_stall(self, which, microseconds, percent=0):
+        """Test aid (include/tetris_hip.h: tetris_debug_stall): idle kernel on chain stream 0..2, on the batch's stream (3) or,
+        which = -1, holding `percent` % of the device's wave slots on a stream of its own."""
+        self._check(self.lib.tetris_debug_stall(self._h, int(which), int(microseconds), int(percent)))
+
     def rollout_is_chained(self, steps_per_launch=1):
         rc = self.lib.tetris_rollout_is_chained(self._h, int(steps_per_launch))
         if rc < 0:
@@ -391,8 +402,9 @@ class TetrisBatch:
         self._check(self.lib.tetris_sync(self._h))
 
     def take_errors(self):
-        """-> TETRIS_ERR_* bits (1 = a garbage queue overflowed, 2 = an episode outran the RNG tables) of games that were ended by
-        a capacity error since the last call; which games: observe()[0]["fifo_overflow"]."""
+        """-> TETRIS_ERR_* bits since the last call: 1 = a garbage queue overflowed, 2 = an episode outran the RNG tables (games
+        ended by a capacity error; which games: observe()[0]["fifo_overflow"]); 4 = a chained rollout call fell back to
+        un-chained launches for some games (results unaffected, chaining is now off for this batch)."""
         bits = C.c_uint32(0)
         self._check(self.lib.tetris_take_errors(self._h, C.byref(bits)))
         return int(bits.value)

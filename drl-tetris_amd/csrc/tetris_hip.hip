@@ -10,6 +10,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <mutex>
 #include <new>
 #include <chrono>
@@ -31,7 +32,8 @@ using namespace te;
 // wave = 64 games): wave w of launch E polls an epoch word until wave w of launch E - 1 has published E - 1.  Every state
 // load / store is agent-scope (`sc1`: written through, read past the per-XCD L2), the storing wave drains its stores
 // (`s_waitcnt vmcnt(0)`) before it publishes — the measured-valid hand-off of MI355X_MICROARCH.md.  Spins are bounded: a wave
-// that gives up poisons its epoch word, raises F_CHAIN and leaves its games untouched, and the host reports an error.
+// that gives up marks its epoch word (CHAIN_ABANDONED), raises F_CHAIN and leaves its games untouched; so does the same wave of
+// every later launch, and the host finishes those games un-chained once the streams have drained (chain_recover).
 #ifndef TE_CHAIN_LANES
 #define TE_CHAIN_LANES 64          // games per wave of k_chain (experiment knob: 32 / 16 = emptier waves, more of them per SIMD)
 #endif
@@ -58,10 +60,7 @@ __global__ __launch_bounds__(64) void k_chain(KArgs a) {
     if (active) policy_draw(a, (uint32_t)i, a.first_step, g.draw0, g.draw1);
     const uint32_t d0 = g.draw0, d1 = g.draw1;
     TE_STAMP_CHAIN(a.epoch, 1);
-    if (!chain_wait(a, (uint32_t)wave)) {
-        if (lane == 0) { ((volatile uint32_t*)a.status)[F_CHAIN] = 1u; st_agent(a.chain + (size_t)wave * CHAIN_STRIDE, CHAIN_POISON); }
-        return;
-    }
+    if (!chain_wait(a, (uint32_t)wave, lane == 0)) return;      // gave up: the games stay as launch E - 1 (or an earlier one) left them
     TE_STAMP_CHAIN(a.epoch, 2);
     if (active) { load_game<P>(geo_of(a), (size_t)i, g, false, P > 1, true, MEM_AGENT, CHAIN_LANES == 64); g.draw0 = d0; g.draw1 = d1; }
 #if defined(TE_PHASE_TRACE)
@@ -78,10 +77,16 @@ __global__ __launch_bounds__(64) void k_chain(KArgs a) {
     TE_STAMP_CHAIN(a.epoch, 6);
 }
 
-// Debug aid (TETRIS_PREQUEUE=1): keeps a stream busy for ~`loops` x 64 clock cycles so that the launches enqueued behind it are all
-// queued before the first one starts — the GPU-paced launch period without any host pacing.
-__global__ void k_blocker(int loops) {
-    for (int k = 0; k < loops; k++) __builtin_amdgcn_s_sleep(1);
+// Measurement / test aid: keeps a stream busy until the HOST sets `*go` (a word in pinned host memory; NULL: no such word) or
+// `ticks` of the 100 MHz real-time clock have passed, whichever comes first.  TETRIS_PREQUEUE=1 parks the chain streams behind it
+// while the host enqueues, so that every launch of the call is queued before the first one starts — the GPU-paced launch period
+// without any host pacing; tetris_debug_stall uses it to hold a stream or the device's wave slots (tests of the give-up path).
+__global__ void k_blocker(const uint32_t* go, unsigned long long ticks) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) {
+        if (go && __hip_atomic_load(go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) break;
+        __builtin_amdgcn_s_sleep(32);
+    }
 }
 
 // Sums the per-game cumulative rollout counters (G_STEPS, G_EPISODE, G_LINES, G_SENT): run once before and once
@@ -220,10 +225,7 @@ __global__ __launch_bounds__(256) void k_duo(KArgs a) {
     uint32_t pd0 = 0, pd1 = 0;
     if (CHAIN) {
         if (active) policy_draw(a, (uint32_t)gi, a.first_step, pd0, pd1);        // while the wave waits for its predecessor
-        if (!chain_wait(a, (uint32_t)wave)) {
-            if (lane == 0) { ((volatile uint32_t*)a.status)[F_CHAIN] = 1u; st_agent(a.chain + (size_t)wave * CHAIN_STRIDE, CHAIN_POISON); }
-            return;
-        }
+        if (!chain_wait(a, (uint32_t)wave, lane == 0)) return;
     }
     if (active) {
         load_game_words<1>(gr, g, ROLL, MEM);
@@ -593,6 +595,7 @@ __global__ __launch_bounds__(256) void k_set_dead(Geo geo, int n, const int32_t*
 
 struct tetris_batch;
 static void chain_release(tetris_batch* b);
+static int chain_recover(tetris_batch* b);
 static thread_local std::string g_err;
 static int fail(int code, const std::string& msg) {
     g_err = msg;
@@ -749,6 +752,12 @@ struct tetris_batch {
     long long chain_capacity = -1;       // wave slots of the device for the chained kernel (computed on first use)
     int chain_depth = 0;                 // launches in flight = streams rotated over (3, or 2 where only two launches fit; 0: not chained)
     bool chain_pending = false;          // chained launches were enqueued since the last drain
+    uint32_t chain_spin_limit = CHAIN_SPIN_LIMIT;     // polls before a waiting wave gives up (tetris_set_chain_spin_limit)
+    // the chained call in progress (or the last one): what chain_recover needs to finish abandoned games un-chained
+    struct { uint32_t epoch0 = 0; uint64_t first_step = 0; int steps_per_launch = 0; uint32_t policy_seed = 0; int ms = 0; } chain_call;
+    bool chain_fell_back = false;        // a chained call was finished un-chained since the last tetris_take_errors (TETRIS_ERR_CHAIN_FELL_BACK)
+    uint32_t* h_chain = nullptr;         // host copy of the epoch words (chain_recover)
+    hipStream_t stall_stream = nullptr;  // tetris_debug_stall(.., -1, ..)
     bool home_async = false;             // asynchronous (_dev) work was enqueued on the batch's stream since the last drain
     bool busy = true;                    // something was enqueued on one of the batch's streams since the last drain
     // Run-ahead gate of the asynchronous entry points: every GATE_GROUP launches an event is recorded; before a new group is
@@ -827,9 +836,13 @@ static bool chain_fits(tetris_batch* b) {
         b->chain_capacity = per_cu > 1 ? (long long)(per_cu - 1) * cus : 0;
     }
     b->chain_depth = 0;
-    for (int d = CHAIN_STREAMS; d >= 2 && !b->chain_depth; d--)
+    // TETRIS_CHAIN_DEPTH=1..3 (measurement aid): at most that many launches in flight.  1 = the chained kernel on ONE stream: its
+    // dispatches are then serialised by the stream, which is what per-dispatch PMC counters need (the TCC counters are chip-wide
+    // and restart with every dispatch, so dispatches that overlap read parts of each other's traffic: profiles/pmc_summary.py).
+    static const int cap = [] { const char* e = getenv("TETRIS_CHAIN_DEPTH"); const int v = e ? atoi(e) : CHAIN_STREAMS; return v < 1 ? 1 : (v > CHAIN_STREAMS ? CHAIN_STREAMS : v); }();
+    for (int d = cap; d >= 1 && !b->chain_depth; d--)
         if (d * waves <= b->chain_capacity) b->chain_depth = d;
-    return b->chain_depth >= 2;
+    return b->chain_depth >= (cap == 1 ? 1 : 2);
 }
 
 // Looks at the flag words WITHOUT enqueuing or waiting for anything: answers a pending "extend the RNG tables" request
@@ -901,9 +914,9 @@ static int finish_call(tetris_batch* b, bool drained = false) {
     b->gate_count = 0; b->gate_pending[0] = b->gate_pending[1] = 0;
     volatile uint32_t* f = b->flags;
     // (F_EXHAUSTED / F_FIFO: capacity errors are confined to the games they happened in — tetris_take_errors)
-    if (f[F_CHAIN]) return fail(TETRIS_E_HIP, "a wave of a chained launch gave up waiting for its predecessor; state is invalid");
-    int rc = service_flags(b);                                  // before the argument error below: an extend request is never dropped
-    if (rc) return rc;
+    int rc = TETRIS_OK;
+    if (f[F_CHAIN] && (rc = chain_recover(b))) return rc;       // waves of a chained launch gave up: their games are finished un-chained
+    if ((rc = service_flags(b))) return rc;                     // before the argument error below: an extend request is never dropped
     if (f[F_BADARG]) {
         f[F_BADARG] = 0;
         return fail(TETRIS_E_ARG, "output capacity exceeded (max_lists / max_keys too small)");
@@ -994,6 +1007,8 @@ int tetris_destroy(tetris_batch* b) {
     for (hipEvent_t e : b->chain_ev) if (e) (void)hipEventDestroy(e);
     for (hipStream_t st : b->chain_stream) if (st) (void)hipStreamDestroy(st);
     (void)hipFree(b->d_chain);
+    free(b->h_chain);
+    if (b->stall_stream) { (void)hipStreamSynchronize(b->stall_stream); (void)hipStreamDestroy(b->stall_stream); }
     Stage* all[] = {&b->s_idx, &b->s_in0, &b->s_in1, &b->s_in2, &b->s_out0, &b->s_out1, &b->s_out2, &b->s_big, &b->s_act0, &b->s_act1, &b->s_act2};
     for (Stage* s : all) s->release();
     if (b->ev0) (void)hipEventDestroy(b->ev0);
@@ -1032,6 +1047,7 @@ static int create_impl(tetris_batch** out, int n_games, int n_players, int heigh
     { const char* e = getenv("TETRIS_NO_DUO"); b->use_duo = !(e && e[0] == '1'); }
     { const char* e = getenv("TETRIS_NO_CHAIN"); b->use_chain = !(e && e[0] == '1'); }
     { const char* e = getenv("TETRIS_GRAPH"); b->use_graph = (e && e[0] == '1'); }
+    { const char* e = getenv("TETRIS_CHAIN_SPIN_LIMIT"); if (e && atoll(e) > 0) b->chain_spin_limit = (uint32_t)atoll(e); }
     b->nw = b->tint ? NWORDS_TINT : NWORDS;
 #define CREATE_TRY(expr)                                                                    \
     do {                                                                                    \
@@ -1101,6 +1117,37 @@ int tetris_set_chained(tetris_batch* b, int on) {
     if (rc) return rc;
     if ((rc = finish_call(b))) return rc;
     b->use_chain = on ? 1 : 0;
+    return TETRIS_OK;
+}
+
+int tetris_set_chain_spin_limit(tetris_batch* b, uint32_t polls) {
+    int rc = check_batch(b, false);
+    if (rc) return rc;
+    if ((rc = finish_call(b))) return rc;
+    b->chain_spin_limit = polls ? polls : CHAIN_SPIN_LIMIT;
+    return TETRIS_OK;
+}
+
+// Test aid (tests of the give-up path of chained launches; nothing in the product calls it): enqueues a kernel that does nothing for
+// `microseconds` — which = 0..2: on that chain stream (the launches the next rollout puts there start late); 3: on the batch's
+// stream; -1: on a stream of its own, as 1024-thread workgroups that take `percent` % of the device's wave slots meanwhile.
+int tetris_debug_stall(tetris_batch* b, int which, int microseconds, int percent) {
+    int rc = check_batch(b);
+    if (rc) return rc;
+    if (which < -1 || which > 3 || microseconds < 0 || microseconds > 2000000 || percent < 0 || percent > 100) return fail(TETRIS_E_ARG, "which / microseconds / percent");
+    const unsigned long long ticks = (unsigned long long)microseconds * 100ull;
+    if (which >= 0) {
+        hipStream_t st = which == 3 ? b->stream : b->chain_stream[which % CHAIN_STREAMS];
+        if (which < 3) b->chain_pending = true;
+        hipLaunchKernelGGL(k_blocker, dim3(1), dim3(64), 0, st, (const uint32_t*)nullptr, ticks);
+    } else {
+        if (!b->stall_stream) HIP_TRY(hipStreamCreateWithFlags(&b->stall_stream, hipStreamNonBlocking));
+        int cus = 0;
+        HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b->device));
+        const int blocks = (int)((long long)cus * 2 * percent / 100);        // 2 x 1024 threads = the 32 wave slots of a CU
+        if (blocks > 0) hipLaunchKernelGGL(k_blocker, dim3((unsigned)blocks), dim3(1024), 0, b->stall_stream, (const uint32_t*)nullptr, ticks);
+    }
+    HIP_TRY(hipGetLastError());
     return TETRIS_OK;
 }
 
@@ -1194,8 +1241,8 @@ int tetris_take_errors(tetris_batch* b, uint32_t* bits) {
     if (!bits) return fail(TETRIS_E_ARG, "bits is NULL");
     if ((rc = finish_call(b))) return rc;
     volatile uint32_t* f = b->flags;
-    *bits = (f[F_FIFO] ? TETRIS_ERR_FIFO : 0u) | (f[F_EXHAUSTED] ? TETRIS_ERR_STREAM : 0u);
-    f[F_FIFO] = 0; f[F_EXHAUSTED] = 0;
+    *bits = (f[F_FIFO] ? TETRIS_ERR_FIFO : 0u) | (f[F_EXHAUSTED] ? TETRIS_ERR_STREAM : 0u) | (b->chain_fell_back ? TETRIS_ERR_CHAIN_FELL_BACK : 0u);
+    f[F_FIFO] = 0; f[F_EXHAUSTED] = 0; b->chain_fell_back = false;
     return TETRIS_OK;
 }
 
@@ -1743,6 +1790,66 @@ int tetris_rollout_is_chained(tetris_batch* b, int steps_per_launch) {
     return rollout_chained(b, steps_per_launch) ? 1 : 0;
 }
 
+// Waves of a chained call gave up waiting (F_CHAIN): with every stream drained, each wave's epoch word names the last launch that
+// finished its games (chain_wait).  The games of the waves that are behind are stepped on to the call's last launch by the
+// un-chained kernel on the batch's stream, group by group (waves that stopped at the same launch), then the epoch words are set
+// to the final epoch and chaining is switched off for this batch (a device that starved a launch once is shared with something:
+// tetris_set_chained(b, 1) switches it back on).  Bit-exact: a wave that gives up has not touched its games.
+static int chain_recover(tetris_batch* b) {
+    volatile uint32_t* f = b->flags;
+    const int lanes = b->P == 1 ? CHAIN_LANES : 32;
+    const int waves = (b->N + lanes - 1) / lanes;
+    hipStream_t const home = b->own_stream;
+    struct StreamGuard { tetris_batch* b; hipStream_t keep; ~StreamGuard() { b->stream = keep; } } guard{b, b->stream};
+    b->stream = home;
+    const size_t bytes = (size_t)waves * CHAIN_STRIDE * sizeof(uint32_t);
+    if (!b->h_chain && !(b->h_chain = (uint32_t*)malloc((((size_t)b->N + 15) / 16) * sizeof(uint32_t) * CHAIN_STRIDE))) return fail(TETRIS_E_HIP, "out of host memory");
+    HIP_TRY(hipMemcpyAsync(b->h_chain, b->d_chain, bytes, hipMemcpyDeviceToHost, home));
+    HIP_TRY(hipStreamSynchronize(home));
+    const uint32_t last = b->chain_epoch, epoch0 = b->chain_call.epoch0;
+    const int S = b->chain_call.steps_per_launch;
+    std::vector<uint32_t> stops;                                  // distinct epochs at which waves stopped, ascending
+    for (int w = 0; w < waves; w++) {
+        const uint32_t c = b->h_chain[(size_t)w * CHAIN_STRIDE] & ~CHAIN_ABANDONED;
+        if (c < epoch0 || c > last) return fail(TETRIS_E_HIP, "chained launches: an epoch word is outside the range of the call that gave up; state is invalid");
+        if (c < last) stops.push_back(c);
+    }
+    std::sort(stops.begin(), stops.end());
+    stops.erase(std::unique(stops.begin(), stops.end()), stops.end());
+    const uint32_t saved_margin = b->margin;
+    struct MarginGuard { tetris_batch* b; uint32_t saved; ~MarginGuard() { b->margin = saved; } } margin_guard{b, saved_margin};
+    const int FUSE = 16;                                          // env-steps per recovery launch (the flag words are read after every launch)
+    if (b->margin < (uint32_t)(2 * FUSE * 2 + 16)) b->margin = (uint32_t)(2 * FUSE * 2 + 16);
+    std::vector<int32_t> idx;
+    for (uint32_t c : stops) {
+        idx.clear();
+        for (int w = 0; w < waves; w++)
+            if ((b->h_chain[(size_t)w * CHAIN_STRIDE] & ~CHAIN_ABANDONED) == c)
+                for (int g = w * lanes; g < (w + 1) * lanes && g < b->N; g++) idx.push_back(g);
+        unsigned long long step = b->chain_call.first_step + (unsigned long long)(c - epoch0) * (unsigned long long)S;
+        unsigned long long todo = (unsigned long long)(last - c) * (unsigned long long)S;
+        while (todo > 0) {
+            const int steps = todo < (unsigned long long)FUSE ? (int)todo : FUSE;
+            const int32_t* d_idx = nullptr;
+            int rc = stage_idx(b, idx.data(), (int)idx.size(), &d_idx);
+            if (rc) return rc;
+            KArgs a = base_args(b, (int)idx.size(), d_idx);
+            a.ms = b->chain_call.ms; a.steps = steps; a.policy_seed = b->chain_call.policy_seed; a.first_step = step;
+            if ((rc = launch_game<M_ROLLOUT>(b, a))) return rc;
+            HIP_TRY(hipStreamSynchronize(home));
+            if ((rc = service_flags(b))) return rc;                // (an extension of the RNG tables is enqueued before the next launch)
+            step += (unsigned long long)steps; todo -= (unsigned long long)steps;
+        }
+    }
+    // every wave's word = the call's last epoch, without the bit (hipMemsetD32: the lines' other words are never read)
+    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)b->d_chain, (int)last, (size_t)waves * CHAIN_STRIDE, home));
+    HIP_TRY(hipStreamSynchronize(home));
+    f[F_CHAIN] = 0;
+    b->chain_fell_back = true;
+    b->use_chain = 0;
+    return TETRIS_OK;
+}
+
 int tetris_rollout_launch(tetris_batch* b, int launches, int steps_per_launch, uint32_t policy_seed, uint64_t first_step,
                           int ms, float* elapsed_ms) {
     const auto t_entry = std::chrono::steady_clock::now();
@@ -1767,11 +1874,20 @@ int tetris_rollout_launch(tetris_batch* b, int launches, int steps_per_launch, u
     // Only when CHAIN_STREAMS launches fit on the device together (chain_fits): a waiting wave keeps its slot, so a launch whose waves
     // wait must never be able to keep its predecessor's waves from being dispatched.
     const bool chained = rollout_chained(b, steps_per_launch) && chain_acquire(b);
-    struct ChainGuard {                           // (released on every return path; the call ends with every chain stream idle)
-        tetris_batch* b; bool held;
-        ~ChainGuard() { if (held) chain_release(b); }
-    } chain_guard{b, chained};
     hipStream_t const home = b->stream;
+    // Every way out of a chained call — errors included — first waits until the chain streams are idle and only then gives up the
+    // device's chaining slot: another batch that took it while launches of this one were still in flight would put more than
+    // chain_depth launches on the device (chain_fits counts on that bound).
+    struct ChainGuard {
+        tetris_batch* b; bool held; hipStream_t home;
+        ~ChainGuard() {
+            b->stream = home;                     // (base_args / launch_game / gate_launch work on b->stream)
+            if (!held) return;
+            if (b->chain_pending)
+                for (int k = 0; k < CHAIN_STREAMS; k++) (void)hipStreamSynchronize(b->chain_stream[k]);
+            chain_release(b);
+        }
+    } chain_guard{b, chained, home};
     if (!chained && b->use_graph && steps_per_launch >= 1) {
         // TETRIS_GRAPH=1 (profiling aid): the launches are captured into HIP graphs of up to 128 kernel nodes and replayed, so the
         // host makes one call per 128 launches.  Under rocprofv3 a plain launch costs the host ~8 us — more than the kernel
@@ -1806,6 +1922,16 @@ int tetris_rollout_launch(tetris_batch* b, int launches, int steps_per_launch, u
         if (elapsed_ms) HIP_TRY(hipEventElapsedTime(elapsed_ms, b->ev0, b->ev1));
         return TETRIS_OK;
     }
+    if (chained) {
+        if (b->chain_epoch + (uint32_t)launches >= CHAIN_EPOCH_MAX || b->chain_epoch + (uint32_t)launches < b->chain_epoch) {
+            // epoch numbers stay below the CHAIN_ABANDONED bit: restart the numbering (every chain stream is idle between calls)
+            HIP_TRY(hipMemsetAsync(b->d_chain, 0, (((size_t)b->N + 15) / 16) * sizeof(uint32_t) * CHAIN_STRIDE, home));
+            b->chain_epoch = 0;
+            b->home_async = true;
+        }
+        b->chain_call.epoch0 = b->chain_epoch; b->chain_call.first_step = first_step; b->chain_call.steps_per_launch = steps_per_launch;
+        b->chain_call.policy_seed = policy_seed; b->chain_call.ms = ms;
+    }
     if (chained && b->home_async) {
         // the chain streams start behind the asynchronous work the batch's stream still holds (after a synchronous call it
         // is empty and nothing has to be ordered)
@@ -1813,20 +1939,22 @@ int tetris_rollout_launch(tetris_batch* b, int launches, int steps_per_launch, u
         for (int k = 0; k < CHAIN_STREAMS; k++) HIP_TRY(hipStreamWaitEvent(b->chain_stream[k], b->chain_ev[CHAIN_STREAMS], 0));
     }
     // Measurement aid (TETRIS_PREQUEUE=1, read per call; bench.py's `launch_us_gpu_paced`): the chain streams are parked behind a
-    // ~5 ms blocker kernel while the host enqueues, so every launch of the call is queued before the first one starts and the
-    // host's launch cost does not enter the period.  No run-ahead gate in such a call (it would wait for the blocker): <= 600 launches.
-    const bool prequeue = getenv("TETRIS_PREQUEUE") != nullptr;
-    if (chained && prequeue && launches <= 600) {
-        hipLaunchKernelGGL(k_blocker, dim3(1), dim3(64), 0, home, 200000);           // ~5 ms
+    // blocker kernel that runs until the host, having enqueued every launch of the call, sets a flag word in pinned memory (or 200 ms
+    // have passed), so every launch is queued before the first one starts and the host's launch cost — 2.5-5 us per launch, ~8 us
+    // under rocprofv3 — does not enter the period.  No run-ahead gate in such a call (it would wait for the blocker): <= 600 launches.
+    const bool prequeue = chained && getenv("TETRIS_PREQUEUE") != nullptr && launches <= 600;
+    if (prequeue) {
+        ((volatile uint32_t*)b->flags)[F_GO] = 0;
+        hipLaunchKernelGGL(k_blocker, dim3(1), dim3(64), 0, home, (const uint32_t*)(b->flags + F_GO), 20000000ull);      // <= 200 ms
         HIP_TRY(hipEventRecord(b->chain_ev[CHAIN_STREAMS], home));
         for (int k = 0; k < CHAIN_STREAMS; k++) HIP_TRY(hipStreamWaitEvent(b->chain_stream[k], b->chain_ev[CHAIN_STREAMS], 0));
         group = 1 << 20;
     }
+    struct GoGuard {                              // (no return path leaves the blocker waiting for its flag)
+        tetris_batch* b; bool armed;
+        ~GoGuard() { if (armed) ((volatile uint32_t*)b->flags)[F_GO] = 1; }
+    } go_guard{b, prequeue};
     HIP_TRY(hipEventRecord(b->ev0, chained ? b->chain_stream[0] : home));
-    struct StreamGuard {                          // base_args / launch_game / gate_launch work on b->stream
-        tetris_batch* b; hipStream_t home;
-        ~StreamGuard() { b->stream = home; }
-    } stream_guard{b, home};
     static const bool timing = getenv("TETRIS_TIMING") != nullptr;         // debug aid: host-side cost of this loop on stderr
     const auto t_begin = std::chrono::steady_clock::now();
     double gate_s = 0.0;
@@ -1839,10 +1967,16 @@ int tetris_rollout_launch(tetris_batch* b, int launches, int steps_per_launch, u
         a.ms = ms; a.steps = steps_per_launch; a.policy_seed = policy_seed;
         a.first_step = first_step + (uint64_t)l * (uint64_t)steps_per_launch;
         if (chained) {
-            a.chain = b->d_chain; a.epoch = ++b->chain_epoch;
+            a.chain = b->d_chain; a.epoch = ++b->chain_epoch; a.chain_spin_limit = b->chain_spin_limit;
             if (b->P == 1) hipLaunchKernelGGL((k_chain<1>), dim3((unsigned)((b->N + CHAIN_LANES - 1) / CHAIN_LANES)), dim3(64), 0, b->stream, a);
             else hipLaunchKernelGGL((k_duo<M_ROLLOUT, true>), dim3((unsigned)((b->N + 31) / 32)), dim3(64), 0, b->stream, a);
-            HIP_TRY(hipGetLastError());
+            const hipError_t le = hipGetLastError();
+            if (le != hipSuccess) {
+                // this launch does not exist: without it no wave could ever publish its epoch, so the numbering steps back
+                // (the launches already enqueued run to their end; ChainGuard waits for them)
+                b->chain_epoch--;
+                return fail(TETRIS_E_HIP, std::string("chained launch: ") + hipGetErrorString(le));
+            }
         } else if ((rc = launch_game<M_ROLLOUT>(b, a)))
             return rc;
     }
@@ -1858,6 +1992,7 @@ int tetris_rollout_launch(tetris_batch* b, int launches, int steps_per_launch, u
         if (b->chain_stream[k] != last) HIP_TRY(hipEventRecord(b->chain_ev[k], b->chain_stream[k]));
     for (int k = 0; k < used; k++) HIP_TRY(hipStreamWaitEvent(home, b->chain_stream[k] != last ? b->chain_ev[k] : b->ev1, 0));
     b->stream = home;
+    if (prequeue) { ((volatile uint32_t*)b->flags)[F_GO] = 1; go_guard.armed = false; }      // everything is queued: go
     const auto t_enq = std::chrono::steady_clock::now();
     {
         auto poll = [](hipEvent_t e) {

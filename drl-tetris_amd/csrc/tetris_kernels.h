@@ -44,6 +44,7 @@ struct KArgs {
     uint32_t game_offset;     // global id of slot 0 (rollout policy / seed schedule)
     uint32_t* chain;          // chained launches: one epoch word per wave (NULL = launches are ordered by the stream)
     uint32_t epoch;           // chained launches: this launch's number; its waves wait for epoch - 1 and publish epoch
+    uint32_t chain_spin_limit; // chained launches: polls of the epoch word before a wave gives up (tetris_set_chain_spin_limit)
     uint32_t* shadow;         // split mode, side 1: post-settle state of the speculative loop-1 pass
     const uint32_t* xw[4];    // split mode: exchange words [n] each: my A, the opponent's A, player 0's B, player 1's B (separate buffers:
                               // the words a kernel wrote and the rows an all-gather delivered are read where they lie, no copies)
@@ -92,7 +93,15 @@ TE_HD void report_status(const KArgs& a, uint32_t st) {
 }
 
 // ---- chained launches (tetris_hip.hip: k_chain): the hand-over of a wave's 64 games from launch E - 1 to launch E
-constexpr uint32_t CHAIN_POISON = 0xFFFFFFFFu;      // a wave gave up waiting: every later launch's wave passes the poison on
+// A wave's epoch word holds the number of the last launch that finished this wave's games (bits 0..30).  CHAIN_ABANDONED (bit 31)
+// is OR-ed into it by a wave that gave up waiting: the waves of every later launch that see the bit pass it on — they leave their
+// games untouched too — and the host, once everything has drained, finishes the games of such waves un-chained from the epoch the
+// low bits name (tetris_hip.hip: chain_recover).  The bit is set with an atomic OR, never by storing a value the wave has read
+// earlier: the predecessor may publish between the last poll and the give-up, and its epoch must survive.  (Should the predecessor
+// publish AFTER the OR, the bit is overwritten; the next launch's wave then waits for an epoch that never comes, gives up on its
+// own bound and sets the bit again; the word still names the right epoch at every moment.)
+constexpr uint32_t CHAIN_ABANDONED = 0x80000000u;
+constexpr uint32_t CHAIN_EPOCH_MAX = 0x7FFF0000u;    // the host restarts the epoch numbering (at a drained point) before it gets here
 // The epoch words of consecutive waves lie CHAIN_STRIDE words apart: one 128-byte line per wave.  Packed (32 waves' words in
 // one line) every publication hit a line that 31 other waves were polling: GPU-paced 4.72 us per launch against 4.50 with one
 // line each at the same poll interval, and with the lines private a SHORT poll interval pays (s_sleep 32: 4.50, 8: 4.24,
@@ -104,20 +113,29 @@ constexpr int CHAIN_STRIDE = TE_CHAIN_STRIDE;
 #ifndef TE_CHAIN_SLEEP
 #define TE_CHAIN_SLEEP 1            // s_sleep between two polls of the epoch word (x 64 cycles)
 #endif
-constexpr int CHAIN_SPIN_LIMIT = 1 << 22;           // polls before a wave gives up (each ~0.5 us: an agent-scope load + a short sleep): ~2 s
+constexpr uint32_t CHAIN_SPIN_LIMIT = 1u << 22;     // default polls before a wave gives up (each ~0.5 us: an agent-scope load + a short sleep): ~2 s
+
+#if defined(__HIP_DEVICE_COMPILE__)
+TE_HD void or_agent(uint32_t* p, uint32_t v) { (void)__hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#else
+TE_HD void or_agent(uint32_t* p, uint32_t v) { *p |= v; }
+#endif
 
 // true when the state of this wave's games as launch E - 1 left it is visible (their stores were `sc1` and drained before the
-// epoch word was written, and the word is polled with an `sc1` load: MI355X_MICROARCH.md, valid forms of an inter-workgroup hand-off)
-TE_HD bool chain_wait(const KArgs& a, uint32_t wave) {
+// epoch word was written, and the word is polled with an `sc1` load: MI355X_MICROARCH.md, valid forms of an inter-workgroup hand-off).
+// false: the wave must leave its games untouched and publish nothing (`marker`: the one lane that records a give-up).
+TE_HD bool chain_wait(const KArgs& a, uint32_t wave, bool marker) {
     const uint32_t want = a.epoch - 1u;
-    for (int spin = 0; spin < CHAIN_SPIN_LIMIT; spin++) {
-        const uint32_t v = ld_agent(a.chain + (size_t)wave * CHAIN_STRIDE);
+    uint32_t* word = a.chain + (size_t)wave * CHAIN_STRIDE;
+    for (uint32_t spin = 0; spin < a.chain_spin_limit; spin++) {
+        const uint32_t v = ld_agent(word);
         if (v == want) return true;
-        if (v == CHAIN_POISON) break;
+        if (v & CHAIN_ABANDONED) return false;              // an earlier launch's wave gave up: nothing to add
 #if defined(__HIP_DEVICE_COMPILE__)
         __builtin_amdgcn_s_sleep(TE_CHAIN_SLEEP);
 #endif
     }
+    if (marker) { or_agent(word, CHAIN_ABANDONED); ((volatile uint32_t*)a.status)[F_CHAIN] = 1u; }
     return false;
 }
 

@@ -77,7 +77,8 @@ enum Flag : int {
     F_EXHAUSTED = 1,   // != 0: a draw index ran past the tables
     F_FIFO = 2,        // != 0: a garbage queue overflowed
     F_BADARG = 3,      // != 0: an output capacity was exceeded (get_actions)
-    F_CHAIN = 4,       // != 0: a wave of a chained launch gave up waiting for its predecessor (results invalid)
+    F_CHAIN = 4,       // != 0: a wave of a chained launch gave up waiting for its predecessor (the host finishes its games un-chained)
+    F_GO = 5,          // written by the HOST: releases the blocker kernel of a pre-queued rollout (TETRIS_PREQUEUE)
     NFLAGS = 8
 };
 

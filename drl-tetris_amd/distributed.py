@@ -88,6 +88,10 @@ class SplitOpponents:
     rank `peer` holds the other player of the same games.  The garbage-line exchange of the reference
     (PythonHandle::distributeLines, PythonHandle.cpp:124-136) and the dead flags of its winner logic become three
     all-gathers of one 32-bit word per board per step (stage protocol: csrc/tetris_engine.h "split mode").
+    The all-gathers run in a process group of the two ranks of the pair only: the words concern nobody else, and over the
+    whole world every GPU would receive world - 1 rows to read one (xGMI is point-to-point: at 8 ranks 7 links' worth of
+    traffic for 1).  `pairs` = every pair of the job, the same list on every rank (default: ranks 2k and 2k + 1) — creating
+    a process group is a collective over the world.
 
     With the `nccl` backend (= RCCL over xGMI) every buffer is a device tensor and the batch runs on torch's current
     stream, so kernels and collectives are stream-ordered without host synchronisation.  With `gloo` (CPU tests, where
@@ -95,12 +99,24 @@ class SplitOpponents:
     """
 
     def __init__(self, n_games, side, peer, dist, height=20, width=10, pieces=(0, 1, 2, 3, 4, 5, 6), seeds=None, device=0,
-                 lib_path=None):
+                 lib_path=None, pairs=None):
         import torch
 
         self.torch, self.dist = torch, dist
         self.n, self.side, self.peer = int(n_games), int(side), int(peer)
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        if pairs is None:
+            pairs = [(2 * k, 2 * k + 1) for k in range(self.world // 2)]
+        mine = tuple(sorted((self.rank, self.peer)))
+        pairs = [tuple(sorted(p)) for p in pairs]
+        if mine not in pairs:
+            raise ValueError(f"rank {self.rank} and its peer {self.peer} are not one of the job's pairs {pairs}")
+        self.group = None
+        for p in pairs:                                   # (every rank creates every group, in the same order)
+            g = dist.new_group(list(p)) if self.world > 2 else None      # two ranks: the world is the pair
+            if p == mine:
+                self.group = g
+        self.row_mine, self.row_peer = (0, 1) if self.rank < self.peer else (1, 0)     # rows of a gather buffer: group ranks ascending
         self.on_gpu = dist.get_backend() == "nccl"
         self.dev = torch.device("cuda", device) if self.on_gpu else torch.device("cpu")
         self.batch = TetrisBatch(n_games, 1, height, width, pieces=pieces, seeds=seeds, device=device, lib_path=lib_path,
@@ -114,17 +130,17 @@ class SplitOpponents:
         # they lie — its own output or the peer's row of a gather buffer — so a step is 3 kernels + 3 all-gathers and nothing
         # else: no copies, no allocation (`zero` is what the side that has nothing to say in an exchange contributes).
         self.a_mine, self.b_mine, self.zero = z(self.n, dt=torch.int32), z(self.n, dt=torch.int32), z(self.n, dt=torch.int32)
-        self.g1, self.g2, self.g3 = (z(self.world, self.n, dt=torch.int32) for _ in range(3))
+        self.g1, self.g2, self.g3 = (z(2, self.n, dt=torch.int32) for _ in range(3))
         B = self.batch
-        opp_a = self.g1[self.peer].data_ptr()
-        b0 = self.b_mine.data_ptr() if self.side == 0 else self.g2[self.peer].data_ptr()
-        b1 = self.g3[self.peer].data_ptr() if self.side == 0 else self.b_mine.data_ptr()
+        opp_a = self.g1[self.row_peer].data_ptr()
+        b0 = self.b_mine.data_ptr() if self.side == 0 else self.g2[self.row_peer].data_ptr()
+        b1 = self.g3[self.row_peer].data_ptr() if self.side == 0 else self.b_mine.data_ptr()
         self.words = B.split_words(self.a_mine.data_ptr(), opp_a, b0, b1)
 
     def _step(self, stage0, stage1, stage2):
         """The stage protocol of one step (csrc/tetris_engine.h "split mode"): exchange 1 = loop-1 words both ways,
         exchange 2 = player 0's tick words, exchange 3 = player 1's tick words."""
-        gather = self.dist.all_gather_into_tensor
+        gather = lambda out, src: self.dist.all_gather_into_tensor(out, src, group=self.group)
         stage0(self.a_mine.data_ptr())
         gather(self.g1.view(-1), self.a_mine)
         if self.side == 0:

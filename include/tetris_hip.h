@@ -48,6 +48,10 @@ extern "C" {
  * goes on untouched.  tetris_take_errors tells whether any game of the batch was ended this way since the last call.   */
 #define TETRIS_ERR_FIFO 1u       /* a 9th garbage packet arrived while 8 were pending: it was dropped */
 #define TETRIS_ERR_STREAM 2u     /* the episode ran past the RNG tables: the pieces dealt in that step are wrong */
+/* Not a capacity error and nothing is wrong with any game: reported once by tetris_take_errors after a chained rollout call had
+ * to finish some of its games un-chained (see tetris_set_chained) — the results are the same, the call was slow, and chained
+ * launches are off for the batch from then on.                                                                          */
+#define TETRIS_ERR_CHAIN_FELL_BACK 4u
 
 #define TETRIS_MAX_H 32
 #define TETRIS_MAX_PLAYERS 4   /* players per game (PythonHandle(n_players, ...): PythonHandle.cpp:5-25) */
@@ -224,34 +228,53 @@ int tetris_rollout_random(tetris_batch *b, int launches, int steps_per_launch, u
 int tetris_rollout_launch(tetris_batch *b, int launches, int steps_per_launch, uint32_t policy_seed,
                           uint64_t first_step, int ms, float *elapsed_ms);
 
-/* Chained launches of the built-in rollout (default on; single-player batches on their own stream, one or more steps per
- * launch): a game's step E depends only on the same game's step E - 1, so consecutive launches rotate over three streams
- * and are ordered per WAVE — the 64 games of a wave wait, inside the kernel, for an epoch word that the same wave
- * of the previous launch publishes after its state stores have drained — instead of per launch by the stream (where every
- * launch waits for the slowest wave of the whole previous launch plus the kernel boundary).  Results are bit-identical.
- * A wave that waits keeps its slot; launches are therefore chained only while three of them — for larger batches two, over
- * two streams — fit on the device together, and a
- * wave never waits unboundedly (after ~3 s it gives up, the call fails with TETRIS_E_HIP and the state is invalid).
- * The fit is computed for a device this process has to itself: kernels of OTHER processes that occupy wave slots of the same
- * GPU can keep a launch from fitting beside its successor; the waiting waves then give up after their bound and the call
- * fails as above (nothing hangs) — share a GPU between processes with chaining off.
- * The three streams overlap only on different hardware queues; they are created with three different stream priorities, which
- * the HIP runtime keeps on separate hardware queues whatever else the process has running (TETRIS_CHAIN_PRIO=0: equal ones).
- * on = 0: every launch on the batch's one stream.  (Environment: TETRIS_NO_CHAIN=1 sets the default to off.)           */
+/* Chained launches of the built-in rollout (default on; single-player batches with one or more steps per launch, two-player
+ * batches with one step per launch, on the batch's own stream): a game's step E depends only on the same game's step E - 1,
+ * so consecutive launches rotate over three streams and are ordered per WAVE — the games of a wave wait, inside the kernel,
+ * for an epoch word that the same wave of the previous launch publishes after its state stores have drained — instead of per
+ * launch by the stream (where every launch waits for the slowest wave of the whole previous launch plus the kernel boundary).
+ * Results are bit-identical.
+ * CHAINING PRESUMES THAT THE DEVICE'S WAVE SLOTS ARE THIS BATCH'S TO USE.  A wave that waits keeps its slot; launches are
+ * therefore chained only while three of them — for larger batches two, over two streams — fit on the device together, and that
+ * fit is computed as if nothing else ran on the GPU: kernels of the host application (a policy network on another stream), of
+ * another process or of a second copy of this library take slots the computation does not know of, and can keep a launch from
+ * being resident beside its successor.  No wave waits unboundedly: after `polls` polls of its epoch word (default 2^22, about
+ * 2 s; tetris_set_chain_spin_limit, or TETRIS_CHAIN_SPIN_LIMIT in the environment when the batch is created) it gives up and
+ * leaves its games untouched, as do the same waves of the launches behind it.  The call then waits for its streams, steps the
+ * games that were left behind to the end of the call with the un-chained kernel, and returns TETRIS_OK with the same results;
+ * tetris_take_errors reports TETRIS_ERR_CHAIN_FELL_BACK once, and chained launches stay off for the batch until
+ * tetris_set_chained(b, 1).  On a GPU that the batch shares with other work, switch chaining off up front:
+ * tetris_set_chained(b, 0) — or TETRIS_NO_CHAIN=1 — costs 5.7 us per launch instead of 4.0 and cannot starve anything.
+ * Side effect a host application may notice: the three streams are created with three different stream priorities (that is how
+ * the HIP runtime is made to keep them on three hardware queues, where alone they overlap; TETRIS_CHAIN_PRIO=0: equal
+ * priorities); the batch's own stream has the default priority.
+ * on = 0: every launch on the batch's one stream.                                                                       */
 int tetris_set_chained(tetris_batch *b, int on);
+/* polls of its predecessor's epoch word after which a waiting wave of a chained launch gives up (0 = the default, 2^22);
+ * one poll is an agent-scope load and a short sleep, about 0.5 us.                                                     */
+int tetris_set_chain_spin_limit(tetris_batch *b, uint32_t polls);
+/* TEST AID for the give-up path above (nothing in the product calls it): enqueues a kernel that idles for `microseconds` —
+ * which = 0..2: on that one of the three chain streams, so the launches the next rollout call puts there start late;
+ * which = 3: on the batch's stream; which = -1: on a stream of its own, as workgroups that hold `percent` % of the device's
+ * wave slots meanwhile (a co-tenant).  Asynchronous.                                                                   */
+int tetris_debug_stall(tetris_batch *b, int which, int microseconds, int percent);
 /* Environment variables read by the library (measurement aids; none changes a result):
  *   TETRIS_NO_CHAIN=1   batches are created with chained launches off (tetris_set_chained)
  *   TETRIS_NO_DUO=1     two-player single steps through k_game<2> (both players of a game in one lane) instead of k_duo
  *   TETRIS_GRAPH=1      un-chained rollout launches are replayed from HIP graphs of 128 kernel nodes (under rocprofv3 a plain
  *                       launch costs the host more than the kernel takes; from a graph the profiled kernels are back to back)
- *   TETRIS_PREQUEUE=1   (read per call) tetris_rollout_launch of <= 600 chained launches parks its streams behind a ~5 ms blocker
- *                       kernel until every launch is queued: the GPU-paced launch period, without the host's launch cost
+ *   TETRIS_PREQUEUE=1   (read per call) tetris_rollout_launch of <= 600 chained launches parks its streams behind a blocker kernel
+ *                       that runs until the host has queued every launch of the call (it then sets a flag word in pinned memory):
+ *                       the GPU-paced launch period, without the host's launch cost
+ *   TETRIS_CHAIN_SPIN_LIMIT=<polls>  default of tetris_set_chain_spin_limit for batches created afterwards
  *   TETRIS_CHAIN_PRIO=0 the chain streams are created with equal priorities (they may then share a hardware queue)
+ *   TETRIS_CHAIN_DEPTH=1..3  at most that many chained launches in flight; 1 = the chained kernel on one stream, i.e. dispatches
+ *                       serialised by the stream (what per-dispatch PMC counters need: profiles/pmc_summary.py)
  *   TETRIS_TIMING=1     tetris_rollout_launch prints its host-side costs (enqueue per launch, gate waits, until drained) to stderr */
 /* 1 if tetris_rollout_launch / tetris_rollout_random would chain launches of `steps_per_launch` steps on this batch, 0 if not
- * (switched off, caller-owned stream, split or colour batch, or not even two launches fit on the device together: a waiting
- * wave keeps its slot, so chaining is only used where it cannot keep the launch it waits for from being dispatched —
- * 64k single-player boards fit, 64k two-player boards do not).                                                          */
+ * (switched off — by the caller or by a fall-back —, caller-owned stream, split or colour batch, or not even two launches fit
+ * on the device together: a waiting wave keeps its slot, so chaining is only used where it cannot keep the launch it waits
+ * for from being dispatched).                                                                                            */
 int tetris_rollout_is_chained(tetris_batch *b, int steps_per_launch);
 
 /* Global id of this batch's game 0 (default 0): the built-in rollout keys its policy and its

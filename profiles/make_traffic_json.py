@@ -1,29 +1,76 @@
 #!/usr/bin/env python3
-"""profiles/<round>/pmc_p{P}_s{S}.json (read by bench.py for roofline.traffic) from a pmc_passes.sh summary.
-usage: make_traffic_json.py <summary.json> <P> <S> <out.json> [kernel-name substring]
-HBM-side bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) KiB: WRITE_SIZE is exact and FETCH_SIZE reads 1/2 on
-gfx950 for this kernel's access pattern — calibrated with profiles/calib.py (zero-step launches moving exactly
-29 words x 4 B x 65536 games = 7424 KiB written, 28 read: WRITE_SIZE 7424 KiB exact, FETCH_SIZE 3610 KiB = 1/2 of the 7168 KiB + kernel arguments), as
-MI355X_MICROARCH.md §HBM prescribes.  The x2 is calibrated for the coalesced state stream; for the scattered
-one-byte RNG-table reads it is an upper bound.  Infinity-Cache hits are included in these fabric-side counters."""
-import json, sys
-summary, P, S, out = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+"""profiles/<round>/pmc_p{P}_s{S}.json (read by bench.py for roofline.traffic) from pmc_passes.sh summaries.
+
+usage: make_traffic_json.py <summary.json of a SERIALISED run> <P> <S> <out.json> <kernel substring> <calib summary.json> [overlapped summary.json]
+
+Bytes at the L2's memory side (fabric), per launch, from the RAW request counters with the expressions ROCm 7.2's counter_defs.yaml
+gives for gfx950 (the medians over the run's dispatches):
+    write = TCC_EA0_WRREQ_64B * 64 + (TCC_EA0_WRREQ - TCC_EA0_WRREQ_64B) * 32                     (= WRITE_SIZE * 1024)
+    read  = TCC_BUBBLE * 128 + (TCC_EA0_RDREQ - TCC_BUBBLE - TCC_EA0_RDREQ_32B) * 64 + TCC_EA0_RDREQ_32B * 32   (= FETCH_SIZE * 1024)
+The read figure is multiplied by a factor CALIBRATED in the same GPU call on zero-step launches of the same kernel, whose traffic is
+known exactly (MI355X_MICROARCH.md, HBM: on gfx950 FETCH_SIZE reports half the bytes of a coalesced streaming read; other access
+widths must be calibrated on a known byte count): factor = known read bytes / read figure of the calibration run.
+The write figure must not be below what the kernel provably stores (stored words x 4 B x games): the script REFUSES such a
+summary (exit 1) — that is how a run whose dispatches overlapped shows itself (counters are chip-wide and restart per dispatch).
+Infinity-Cache hits are inside these fabric-side counters (the 10 MB state of 64k boards is resident there): HBM proper sees less."""
+import json
+import sys
+
+summary, P, S, out, want, calib = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5], sys.argv[6]
+overlapped = sys.argv[7] if len(sys.argv) > 7 else None
+GAMES = 65536
+STORED_WORDS = {1: 25 + 3, 2: 2 * 27 + 3}       # words every launch stores per game: hot board words + game words
+
+
+def med(k, c):
+    return k[c + "__stats"]["median"]
+
+
+def pick(d, sub):
+    names = [n for n in d if sub in n]
+    if not names:
+        sys.exit(f"no kernel matching {sub!r} in {list(d)}")
+    return names[0], d[names[0]]
+
+
+def fabric_bytes(k):
+    wr, wr64 = med(k, "TCC_EA0_WRREQ_sum"), med(k, "TCC_EA0_WRREQ_64B_sum")
+    rd, rd32, bub = med(k, "TCC_EA0_RDREQ_sum"), med(k, "TCC_EA0_RDREQ_32B_sum"), med(k, "TCC_BUBBLE_sum")
+    return wr64 * 64 + (wr - wr64) * 32, bub * 128 + (rd - bub - rd32) * 64 + rd32 * 32
+
+
 d = json.load(open(summary))
-want = sys.argv[5] if len(sys.argv) > 5 else None
-names = [name for name in d if (want in name if want else (f"k_game<{P}, 6" in name or "k_chain" in name or "k_duo<6" in name))]
-k = d[names[0]]
+name, k = pick(d, want)
+cname, ck = pick(json.load(open(calib)), want.split("<")[0])
+floor = STORED_WORDS[P] * 4 * GAMES
+write, read_raw = fabric_bytes(k)
+cwrite, cread_raw = fabric_bytes(ck)
+# zero-step launches: every stored word was loaded (the step's table / start-word reads do not happen), plus one epoch word per wave
+known_read = (STORED_WORDS[P] - (1 if P == 1 else 0)) * 4 * GAMES       # (1-player kernels store W_MIN_REMAINING without loading it)
+factor = known_read / cread_raw
 res = {
-    "kernel": names[0], "steps_per_launch": S, "games": 65536,
-    "FETCH_SIZE_KiB_raw": k["FETCH_SIZE"], "WRITE_SIZE_KiB": k["WRITE_SIZE"],
-    "fetch_correction": 2.0,
-    "hbm_bytes_per_launch": int((2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024),
-    "TCC_HIT_sum": k.get("TCC_HIT_sum"), "TCC_MISS_sum": k.get("TCC_MISS_sum"),
-    "TCC_EA0_RDREQ_sum": k.get("TCC_EA0_RDREQ_sum"), "TCC_EA0_WRREQ_sum": k.get("TCC_EA0_WRREQ_sum"),
+    "kernel": name, "steps_per_launch": S, "games": GAMES, "players": P,
+    "dispatches_serialised": True, "dispatches": k["_dispatches"],
+    "write_bytes": int(write), "write_bytes_floor_stored_words": floor,
+    "WRITE_SIZE_KiB_median": med(k, "WRITE_SIZE") if "WRITE_SIZE__stats" in k else None,
+    "read_bytes_raw": int(read_raw), "read_factor_calibrated": factor,
+    "FETCH_SIZE_KiB_median": med(k, "FETCH_SIZE") if "FETCH_SIZE__stats" in k else None,
+    "calibration": {"kernel": cname, "write_bytes": int(cwrite), "read_bytes_raw": int(cread_raw), "known_read_bytes": known_read,
+                    "known_write_bytes": floor, "source": calib},
+    "hbm_bytes_per_launch": int(write + factor * read_raw),
+    "counters_median": {c[:-7]: v["median"] for c, v in k.items() if c.endswith("__stats")},
+    "counters_min_max": {c[:-7]: [v["min"], v["max"]] for c, v in k.items() if c.endswith("__stats")},
     "source": summary,
 }
-for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_WAVES", "SQ_WAVE_CYCLES",
-          "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "GRBM_GUI_ACTIVE"):
-    if c in k:
-        res[c] = k[c]
+if overlapped:
+    oname, ok = pick(json.load(open(overlapped)), "k_chain" if P == 1 else "k_duo")
+    res["overlapped_run_for_comparison"] = {
+        "kernel": oname, "source": overlapped, "note": "three chain streams: dispatches overlap, chip-wide counters restart per dispatch — NOT used",
+        "counters": {c[:-7]: {s: v[s] for s in ("n", "min", "median", "max", "mean")} for c, v in ok.items() if c.endswith("__stats") and c.startswith("TCC")}}
+if write < floor:
+    json.dump(res, open(out + ".refused", "w"), indent=1)
+    sys.exit(f"REFUSED: write figure {int(write)} B per launch is below the {floor} B the kernel provably stores ({STORED_WORDS[P]} words x 4 B x {GAMES} games)")
+if abs(cwrite - floor) > 0.02 * floor:
+    sys.exit(f"REFUSED: the calibration run wrote {int(cwrite)} B, expected {floor} B")
 json.dump(res, open(out, "w"), indent=1)
-print(out, res["hbm_bytes_per_launch"])
+print(out, res["hbm_bytes_per_launch"], "write", int(write), "read", int(factor * read_raw), "factor", round(factor, 3))

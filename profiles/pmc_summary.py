@@ -1,29 +1,34 @@
 #!/usr/bin/env python3
-"""Averages rocprofv3 --pmc counter_collection CSVs per kernel -> <dir>/summary.json (+ printed).
-FETCH_SIZE/WRITE_SIZE are in KiB-like units of 1024 B?  rocprofv3 reports FETCH_SIZE/WRITE_SIZE in KB;
-per MI355X_MICROARCH.md §HBM the gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x — both the raw
-and the x2-corrected read bytes are written out."""
+"""Per-kernel, per-counter statistics of rocprofv3 --pmc counter_collection CSVs -> <dir>/summary.json (+ printed).
+
+Every dispatch is kept as a sample: n, mean, min, median, max per (kernel, counter).  A mean alone hid round 2's defect: chained
+launches overlap on three streams, the TCC counters are chip-wide and are restarted per dispatch, so a dispatch that overlaps
+another one reads a part of its own traffic (WRITE_SIZE 4 516 KiB for a kernel that stores 7 168 KiB).  Traffic figures are
+therefore taken from runs whose dispatches are serialised (TETRIS_CHAIN_DEPTH=1 or TETRIS_NO_CHAIN=1) and the spread of the
+overlapped run is shown beside them.  Raw counters only; byte figures are derived in make_traffic_json.py."""
 import csv
 import glob
 import json
 import os
+import statistics
 import sys
 from collections import defaultdict
 
 d = sys.argv[1]
-acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
+acc = defaultdict(lambda: defaultdict(list))
 for f in glob.glob(os.path.join(d, "pass*", "**", "*counter_collection.csv"), recursive=True):
     for row in csv.DictReader(open(f)):
-        k = row["Kernel_Name"]
-        a = acc[k][row["Counter_Name"]]
-        a[0] += float(row["Counter_Value"]); a[1] += 1
+        acc[row["Kernel_Name"]][row["Counter_Name"]].append(float(row["Counter_Value"]))
 out = {}
 for k, cs in acc.items():
-    out[k] = {c: v[0] / max(1, v[1]) for c, v in cs.items()}
-    out[k]["_dispatches"] = max(v[1] for v in cs.values())
+    out[k] = {"_dispatches": max(len(v) for v in cs.values())}
+    for c, v in cs.items():
+        out[k][c] = statistics.fmean(v)                      # (the key a round-2 reader expects: the mean)
+        out[k][c + "__stats"] = {"n": len(v), "mean": statistics.fmean(v), "min": min(v), "median": statistics.median(v), "max": max(v)}
 json.dump(out, open(os.path.join(d, "summary.json"), "w"), indent=1)
 for k, cs in out.items():
-    if "k_game" in k or "k_chain" in k or "k_duo" in k:
+    if any(t in k for t in ("k_game", "k_chain", "k_duo", "k_split")):
         print(k)
         for c, v in sorted(cs.items()):
-            print(f"   {c:28s} {v:16.1f}")
+            if c.endswith("__stats"):
+                print(f"   {c[:-7]:28s} n {v['n']:5d}  mean {v['mean']:14.1f}  min {v['min']:14.1f}  median {v['median']:14.1f}  max {v['max']:14.1f}")

@@ -58,3 +58,44 @@ def test_two_ranks_under_torch_distributed_run():
     line = _run(cmd, {"BENCH_DIST_BACKEND": "gloo"})
     _check(line, 2, 1024, 5, 1, 2)
     assert line["cpu_baseline"] is None                # rank 0 at N=1 only
+
+
+def test_plain_gpus_2_starts_its_own_two_ranks():
+    """`python bench.py --gpus 2` with NO launcher: the script spawns its ranks itself and rank 0's single line says n_gpus 2."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(BENCH_LIB_PATH=ge.build_harness(), BENCH_DIST_BACKEND="gloo")
+    out = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--games", "1024", "--steps", "5", "--warmup", "1", "--cpu-seconds", "0"],
+                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    _check(json.loads(lines[0]), 2, 1024, 5, 1, 1)
+
+
+def test_plain_gpus_4_split_workload_runs_two_pairs():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(BENCH_LIB_PATH=ge.build_harness(), BENCH_DIST_BACKEND="gloo")
+    out = subprocess.run([sys.executable, "bench.py", "--gpus", "4", "--workload", "split", "--games", "512", "--steps", "4", "--warmup", "1"],
+                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 4 and line["env_steps_counted_on_device"] == 2 * 512 * 4 and "pair" in line["config"]["parallelism"]
+
+
+def test_more_ranks_than_devices_is_an_error_not_a_smaller_run():
+    """Without the rehearsal library the parent counts the visible GPUs before it starts anything: asking for more is rc != 0
+    and no JSON line (a run on fewer GPUs that calls itself --gpus N would poison a scaling curve)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "BENCH_LIB_PATH")}
+    out = subprocess.run([sys.executable, "bench.py", "--gpus", "64", "--steps", "5", "--warmup", "1", "--cpu-seconds", "0"],
+                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode != 0 and "GPU(s) visible" in out.stderr
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+
+
+def test_world_size_that_differs_from_gpus_is_an_error():
+    env = dict(os.environ, BENCH_LIB_PATH=ge.build_harness(), BENCH_DIST_BACKEND="gloo", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--games", "256", "--steps", "2", "--warmup", "0", "--cpu-seconds", "0"],
+                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode != 0 and "WORLD_SIZE" in out.stderr

@@ -145,3 +145,42 @@ def test_split_rollout_equals_oracle_two_player_rollout(tmp_path):
             assert np.array_equal(got[side]["rec"][f][:, 0], rec[f][:, side]), (side, f)
         assert np.array_equal(got[side]["rec"]["field"][:, 0] > 0, rec["field"][:, side] > 0)
         assert np.array_equal(got[side]["ro"], ro) and np.array_equal(got[side]["lw"], lw)
+
+
+def _pairs_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ge.ROOT)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mod = __import__("importlib").import_module("drl-tetris_amd.distributed")
+    pair = rank // 2
+    so = mod.SplitOpponents(N, side=rank % 2, peer=rank ^ 1, dist=dist, seeds=mod.episode_seeds(pair * N, N), lib_path=ge.build_harness())
+    assert so.group is not None and so.g1.shape == (2, N)      # the exchange runs in the pair's own group and moves the peer's row only
+    so.batch.set_game_offset(pair * N)
+    so.rollout(STEPS_ROLLOUT // 3)
+    so.rollout(STEPS_ROLLOUT - STEPS_ROLLOUT // 3, first_step=STEPS_ROLLOUT // 3)
+    rec, ro, lw = so.batch.observe()
+    np.savez(os.path.join(out_dir, f"pairs{rank}.npz"), rec=rec, ro=ro, lw=lw, totals=so.batch.rollout_totals())
+    so.close()
+    dist.destroy_process_group()
+
+
+def test_two_pairs_exchange_in_pair_local_groups(tmp_path):
+    """Four ranks = two pairs (BASELINE config 5's shape at 8 GPUs is four): ranks 2k / 2k + 1 hold player 0 / player 1 of games
+    [k N, (k + 1) N) and all-gather with each other only (a process group per pair).  Together they must equal ONE oracle rollout
+    of 2 N two-player games."""
+    ge.build_harness()
+    world = 4
+    mp.spawn(_pairs_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    ref = orc.OracleBatch(2 * N, 2, 20, 10, seeds=orc.episode_seed(np.arange(2 * N), 0))
+    _, want = ref.rollout_random(STEPS_ROLLOUT)
+    rec, ro, lw = ref.observe()
+    got = [np.load(os.path.join(str(tmp_path), f"pairs{r}.npz")) for r in range(world)]
+    assert sum(int(got[r]["totals"][0]) for r in (0, 2)) == int(want[0]) == 2 * N * STEPS_ROLLOUT
+    assert sum(int(got[r]["totals"][1]) for r in (0, 2)) == int(want[1])
+    assert sum(int(g["totals"][2]) for g in got) == int(want[2]) and sum(int(g["totals"][3]) for g in got) == int(want[3])
+    for r in range(world):
+        sl, side = slice((r // 2) * N, (r // 2 + 1) * N), r % 2
+        for f in FIELDS:
+            assert np.array_equal(got[r]["rec"][f][:, 0], rec[f][sl, side]), (r, f)
+        assert np.array_equal(got[r]["rec"]["field"][:, 0] > 0, rec["field"][sl, side] > 0)
+        assert np.array_equal(got[r]["ro"], ro[sl]) and np.array_equal(got[r]["lw"], lw[sl])
