@@ -1184,19 +1184,20 @@ int tetris_set_stream(tetris_batch* b, void* hip_stream, int external) {
 
 static int split_stage_launch(tetris_batch* b, int stage, KArgs& a, const uint32_t* const d_words[4], uint32_t* d_out) {
     if (!b->split) return fail(TETRIS_E_ARG, "not a split batch (tetris_create_split)");
-    if (stage < 0 || stage > 2) return fail(TETRIS_E_ARG, "stage must be 0, 1 or 2");
-    if (stage < 2 && !d_out) return fail(TETRIS_E_ARG, "stages 0 and 1 need d_out");
-    // words a stage reads: stage 1 = both A words (+ player 0's B on side 1); stage 2 = the opponent's B
-    if (stage > 0 && !d_words) return fail(TETRIS_E_ARG, "stages 1 and 2 need d_words");
+    if (stage < 0 || stage > 3) return fail(TETRIS_E_ARG, "stage must be 0, 1, 2 or 3 (= 2 of this step + 0 of the next)");
+    if (stage != 2 && !d_out) return fail(TETRIS_E_ARG, "stages 0, 1 and 3 need d_out");
+    // words a stage reads: stage 1 = both A words (+ player 0's B on side 1); stages 2 and 3 = the opponent's B
+    if (stage > 0 && !d_words) return fail(TETRIS_E_ARG, "stages 1, 2 and 3 need d_words");
     if (stage == 1 && (!d_words[0] || !d_words[1] || (b->side == 1 && !d_words[2]))) return fail(TETRIS_E_ARG, "stage 1 needs both A words (and player 0's B words on side 1)");
-    if (stage == 2 && !d_words[b->side == 0 ? 3 : 2]) return fail(TETRIS_E_ARG, "stage 2 needs the opponent's B words");
+    if (stage >= 2 && !d_words[b->side == 0 ? 3 : 2]) return fail(TETRIS_E_ARG, "stages 2 and 3 need the opponent's B words");
     b->home_async = true;
     for (int k = 0; k < 4; k++) a.xw[k] = d_words ? d_words[k] : nullptr;
-    a.shadow = b->d_shadow; a.xout = d_out;
+    a.shadow = b->d_shadow; a.xout = d_out; a.split_side = b->side;
     dim3 grid((unsigned)((b->N + 255) / 256)), block(256);
     if (stage == 0) hipLaunchKernelGGL((k_split<0, false>), grid, block, 0, b->stream, a);
     else if (stage == 1) hipLaunchKernelGGL((k_split<1, false>), grid, block, 0, b->stream, a);
-    else hipLaunchKernelGGL((k_split<2, false>), grid, block, 0, b->stream, a);
+    else if (stage == 2) hipLaunchKernelGGL((k_split<2, false>), grid, block, 0, b->stream, a);
+    else hipLaunchKernelGGL((k_split<3, false>), grid, block, 0, b->stream, a);
     HIP_TRY(hipGetLastError());
     return TETRIS_OK;
 }
@@ -1205,7 +1206,7 @@ int tetris_split_stage_dev(tetris_batch* b, int stage, const uint8_t* d_rot, con
                            const uint32_t* const d_words[4], uint32_t* d_out, uint8_t* d_done, uint8_t* d_lines, uint8_t* d_dead) {
     int rc = check_batch(b);
     if (rc) return rc;
-    if (stage == 0 && (!d_rot || !d_trans)) return fail(TETRIS_E_ARG, "stage 0 needs rot/trans");
+    if ((stage == 0 || stage == 3) && (!d_rot || !d_trans)) return fail(TETRIS_E_ARG, "stages 0 and 3 need rot/trans (stage 3: of the NEXT step)");
     KArgs a = base_args(b, b->N, nullptr);
     a.rot = d_rot; a.trans = d_trans; a.player = d_acting; a.ms = ms;
     a.done = d_done; a.lines = d_lines; a.dead = d_dead;

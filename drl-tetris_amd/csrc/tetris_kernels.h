@@ -45,7 +45,8 @@ struct KArgs {
     uint32_t* chain;          // chained launches: one epoch word per wave (NULL = launches are ordered by the stream)
     uint32_t epoch;           // chained launches: this launch's number; its waves wait for epoch - 1 and publish epoch
     uint32_t chain_spin_limit; // chained launches: polls of the epoch word before a wave gives up (tetris_set_chain_spin_limit)
-    uint32_t* shadow;         // split mode, side 1: post-settle state of the speculative loop-1 pass
+    uint32_t* shadow;         // split mode, side 1: the player words as they were before the speculative loop-1 pass (rollback copy)
+    int split_side;           // split mode: the player index this batch holds
     const uint32_t* xw[4];    // split mode: exchange words [n] each: my A, the opponent's A, player 0's B, player 1's B (separate buffers:
                               // the words a kernel wrote and the rows an all-gather delivered are read where they lie, no copies)
     uint32_t* xout;           // split mode: this stage's word per board [n]
@@ -297,53 +298,78 @@ TE_HD void game_run(const KArgs& a, int i, const uint32_t* shapes, Game<P>& g, L
     report_status(a, g.status);
 }
 
-// Split mode (opponents on different GPUs, tetris_engine.h): one stage of a step for the side this batch holds.
+// Split mode (opponents on different GPUs, tetris_engine.h): one stage of a step for the side this batch holds (a.split_side).
+//   STAGE 0 = A, 1 = B, 2 = C (tetris_engine.h "split mode");  STAGE 3 = C of step s followed by A of step s + 1 in one pass over
+//   the state: C needs only the peer's last exchange word and A of the next step only what C leaves behind, both local once the
+//   gather has landed — a step of a device-driven loop is then TWO kernels (B, C+A) and two state round trips instead of three.
+// Player 1's loop-1 pass (stage A) is speculative: the reference skips it when player 0 died in loop 1 (PythonHandle.cpp:153-156),
+// which side 1 only learns from the exchange.  Side 1 therefore keeps the board as it was BEFORE the pass (post-make, pre-settle)
+// in the shadow array and continues from the main state; only a game whose player 0 did die reloads the shadow (rare: a lane's
+// second load, not a second state array on the critical path — stage B's loads do not wait for the exchange word).
+template <bool TINT>
+TE_HD void split_stage_a(const KArgs& a, const Ctx& cx, int i, Game<1>& g, int side, unsigned long long step) {
+    Player& q = g.pl[0];
+    const uint32_t sent_before = q.lines_sent;
+    int acting, r, t;
+    if (a.rot) { acting = a.player ? a.player[i] : 0; r = a.rot[i] & 3; t = a.trans[i]; }
+    else {          // built-in synthetic policy, identical on both sides of a game
+        uint32_t w[4];
+        philox4x32_10(a.policy_seed, a.game_offset + (uint32_t)i, (uint32_t)step, (uint32_t)(step >> 32), w);
+        r = (int)(w[0] & 3u); t = (int)(w[1] % 10u); acting = (int)(step % 2ull);
+    }
+    prefetch_next(cx, q, g.seed16, g.status);
+    if (!g.round_over && !q.dead && acting == side) play_rt(cx, q, r, t);
+    if (side == 1) {                                      // rollback copy: the player words only (the game words are not speculative)
+        Geo geo = geo_of(a, a.shadow);
+        geo.P = 1;
+        const Ref br = board_ref(geo, 0, (size_t)i);
+        store_player(br.s, br.o, br.ws, q, TINT);
+    }
+    a.xout[i] = split_settle(cx, g);
+    // rollout counter: side 1's loop-1 lines are counted at stage B, once it knows the pass is committed
+    if (side == 0) g.add_sent += (q.lines_sent - sent_before) & 0xFFFFu;
+}
+
 template <int STAGE, bool TINT = false>
 TE_HD void split_body(const KArgs& a, int i, const uint32_t* shapes) {
     Ctx cx = make_ctx(a, shapes, TINT);
     Game<1> g;
-    const uint32_t my_a = STAGE > 0 ? a.xw[0][i] : 0u;
-    const uint32_t opp_a = STAGE > 0 ? a.xw[1][i] : 0u;
-    // side 1 continues from its speculative post-settle state unless player 0 died in loop 1
-    const uint32_t meta = word_at(game_ref(geo_of(a), (size_t)i), G_META);
-    const int side = (int)((meta >> 21) & 1u);
-    const bool from_shadow = STAGE == 1 && side == 1 && !(opp_a & XW_DIED);
-    const bool counting = STAGE == 2 && a.steps;         // built-in rollout: G_STEPS is kept by the last stage
-    load_game<1>(geo_of(a, from_shadow ? a.shadow : a.state), (size_t)i, g, TINT, true, counting);
+    const int side = a.split_side;
+    const bool counting = (STAGE == 2 || STAGE == 3) && a.steps;         // built-in rollout: G_STEPS is kept by stage C
+    load_game<1>(geo_of(a), (size_t)i, g, TINT, true, counting);
     Player& q = g.pl[0];
-    const uint32_t sent_before = q.lines_sent;
     if (STAGE == 0) {
-        int acting, r, t;
-        if (a.rot) { acting = a.player ? a.player[i] : 0; r = a.rot[i] & 3; t = a.trans[i]; }
-        else {          // built-in synthetic policy, identical on both sides of a game
-            uint32_t w[4];
-            philox4x32_10(a.policy_seed, a.game_offset + (uint32_t)i, (uint32_t)a.first_step, (uint32_t)(a.first_step >> 32), w);
-            r = (int)(w[0] & 3u); t = (int)(w[1] % 10u); acting = (int)(a.first_step % 2ull);
-        }
-        prefetch_next(cx, q, g.seed16, g.status);
-        if (!g.round_over && !q.dead && acting == side) play_rt(cx, q, r, t);
-        if (side == 1) store_game<1>(geo_of(a), (size_t)i, g, TINT);        // post-make, pre-settle
-        a.xout[i] = split_settle(cx, g);
-        // rollout counter: side 1's loop-1 pass is speculative and the game words are not shadowed, so side 1 counts
-        // these lines at stage 1, once it knows the pass is committed
-        if (side == 0) g.add_sent += (q.lines_sent - sent_before) & 0xFFFFu;
-        store_game<1>(geo_of(a, side == 1 ? a.shadow : a.state), (size_t)i, g, TINT);
+        split_stage_a<TINT>(a, cx, i, g, side, a.first_step);
+        store_game<1>(geo_of(a), (size_t)i, g, TINT);
     } else if (STAGE == 1) {
+        const uint32_t my_a = a.xw[0][i], opp_a = a.xw[1][i];
         uint32_t w;
         if (side == 0) {
+            const uint32_t sent_before = q.lines_sent;
             const bool i_died = (my_a & XW_DIED) != 0;
             const int in = (!i_died && (opp_a & XW_RAN) && !(opp_a & XW_DIED)) ? xw_sent(opp_a) : 0;
             w = split_tick(cx, g, a.ms, in);
+            g.add_sent += (q.lines_sent - sent_before) & 0xFFFFu;
         } else {
             const uint32_t opp_b = a.xw[2][i];
+            const bool committed = !(opp_a & XW_DIED);
+            if (!committed) {                             // player 0 died in loop 1: player 1 did not run (:153-156) — back to the copy
+                Geo geo = geo_of(a, a.shadow);
+                geo.P = 1;
+                const Ref br = board_ref(geo, 0, (size_t)i);
+                const uint32_t keep = g.status;
+                load_player(br.s, br.o, br.ws, q, TINT);
+                g.status = keep;
+            }
+            const uint32_t sent_before = q.lines_sent;
             const int in1 = ((opp_a & XW_RAN) && !(opp_a & XW_DIED)) ? xw_sent(opp_a) : 0;
             if (!g.round_over && in1 > 0) q.incoming = q.incoming + (float)in1 / 1.0f;   // loop 1, PythonHandle.cpp:121
             const int in2 = (opp_b & XW_DIED) ? 0 : xw_sent(opp_b);                      // loop 2, :175
-            if (from_shadow && (my_a & XW_RAN) && !(my_a & XW_DIED)) g.add_sent += (uint32_t)xw_sent(my_a);   // committed loop-1 lines
+            if (committed && (my_a & XW_RAN) && !(my_a & XW_DIED)) g.add_sent += (uint32_t)xw_sent(my_a);   // committed loop-1 lines
             w = split_tick(cx, g, a.ms, in2);
+            g.add_sent += (q.lines_sent - sent_before) & 0xFFFFu;
         }
         a.xout[i] = w;
-        g.add_sent += (q.lines_sent - sent_before) & 0xFFFFu;
         store_game<1>(geo_of(a), (size_t)i, g, TINT);
     } else {
         const uint32_t opp_b = a.xw[side == 0 ? 3 : 2][i];
@@ -357,6 +383,7 @@ TE_HD void split_body(const KArgs& a, int i, const uint32_t* shapes) {
             if (!q.dead) g.add_lines += (unsigned)q.reward;
             if (done) { g.episode++; reset_split(cx, g, episode_seed(a.game_offset + (uint32_t)i, g.episode)); }
         }
+        if (STAGE == 3) split_stage_a<TINT>(a, cx, i, g, side, a.first_step + 1ull);      // stage A of the NEXT step
         store_game<1>(geo_of(a), (size_t)i, g, TINT, true, counting);
     }
     report_status(a, g.status);

@@ -137,11 +137,9 @@ class SplitOpponents:
         b1 = self.g3[self.row_peer].data_ptr() if self.side == 0 else self.b_mine.data_ptr()
         self.words = B.split_words(self.a_mine.data_ptr(), opp_a, b0, b1)
 
-    def _step(self, stage0, stage1, stage2):
-        """The stage protocol of one step (csrc/tetris_engine.h "split mode"): exchange 1 = loop-1 words both ways,
-        exchange 2 = player 0's tick words, exchange 3 = player 1's tick words."""
+    def _exchange_and_tick(self, stage1):
+        """Exchange 1 (loop-1 words both ways), stage B of player 0, exchange 2 (its tick words), stage B of player 1, exchange 3."""
         gather = lambda out, src: self.dist.all_gather_into_tensor(out, src, group=self.group)
-        stage0(self.a_mine.data_ptr())
         gather(self.g1.view(-1), self.a_mine)
         if self.side == 0:
             stage1(self.b_mine.data_ptr())
@@ -151,6 +149,12 @@ class SplitOpponents:
             gather(self.g2.view(-1), self.zero)
             stage1(self.b_mine.data_ptr())
             gather(self.g3.view(-1), self.b_mine)
+
+    def _step(self, stage0, stage1, stage2):
+        """The stage protocol of one step (csrc/tetris_engine.h "split mode"): exchange 1 = loop-1 words both ways,
+        exchange 2 = player 0's tick words, exchange 3 = player 1's tick words."""
+        stage0(self.a_mine.data_ptr())
+        self._exchange_and_tick(stage1)
         stage2()
 
     def step_rt(self, rot, trans, acting, ms=400):
@@ -168,16 +172,23 @@ class SplitOpponents:
 
     def rollout(self, steps, first_step=0, policy_seed=0xD71, ms=400):
         """`steps` env-steps of the built-in synthetic rollout on every game (policy, acting player and auto-reset are
-        computed on the device, identically on both sides): per step three kernels and three all-gathers, no copies and no host
+        computed on the device, identically on both sides): per step two kernels and three all-gathers, no copies and no host
         synchronisation in between.  -> seconds (wall, after a final stream sync)."""
         t, B, w = self.torch, self.batch, self.words
         if self.on_gpu:
             t.cuda.current_stream(self.dev).synchronize()
         t0 = time.perf_counter()
-        for s in range(first_step, first_step + steps):
-            self._step(lambda out: B.split_rollout_stage(0, s, out=out, policy_seed=policy_seed, ms=ms),
-                       lambda out: B.split_rollout_stage(1, s, words=w, out=out, policy_seed=policy_seed, ms=ms),
-                       lambda: B.split_rollout_stage(2, s, words=w, policy_seed=policy_seed, ms=ms))
+        # per step TWO kernels and three all-gathers: stage B, and stage C fused with stage A of the next step (stage 3: one pass
+        # over the state instead of two); the call's first step starts with a plain stage A, its last one ends with a plain stage C
+        end = first_step + steps
+        if steps > 0:
+            B.split_rollout_stage(0, first_step, out=self.a_mine.data_ptr(), policy_seed=policy_seed, ms=ms)
+        for s in range(first_step, end):
+            self._exchange_and_tick(lambda out: B.split_rollout_stage(1, s, words=w, out=out, policy_seed=policy_seed, ms=ms))
+            if s + 1 < end:
+                B.split_rollout_stage(3, s, words=w, out=self.a_mine.data_ptr(), policy_seed=policy_seed, ms=ms)
+            else:
+                B.split_rollout_stage(2, s, words=w, policy_seed=policy_seed, ms=ms)
         if self.on_gpu:
             t.cuda.current_stream(self.dev).synchronize()
         return time.perf_counter() - t0

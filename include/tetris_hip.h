@@ -290,9 +290,13 @@ int tetris_set_game_offset(tetris_batch *b, uint64_t first_game_id);
  *   stage 0: key interpreter for the acting side ([8]*r+[2]+[3]*t+[7]) + loop 1 (side 1 speculatively) -> words A
  *   stage 1: delayCheck of my player.  Side 0 runs it after the A exchange, side 1 after player 0's B words arrived
  *   stage 2: lines arriving after my tick, winner / round_over -> done[n], lines[n], dead[n] (any may be NULL)
+ *   stage 3: stage 2 of this step and stage 0 of the NEXT step in one launch (one pass over the state instead of two): for
+ *            loops that know the next action when a step ends — d_rot / d_trans / d_acting are the next step's, d_done /
+ *            d_lines / d_dead describe the step that ends, d_out receives the next step's A words.  A step of such a loop
+ *            is two launches (stage 1, stage 3) and three exchanges.
  * d_words: HOST array of four device pointers to uint32 [n] — my A words, the opponent's A words, player 0's B words,
  * player 1's B words (entries a stage does not read may be NULL): the words a stage wrote (d_out) and the rows an
- * all-gather delivered are read where they lie, nothing is copied in between.  d_out [n]: this stage's words (stages 0, 1).
+ * all-gather delivered are read where they lie, nothing is copied in between.  d_out [n]: this stage's words (stages 0, 1, 3).
  * All data pointers are device pointers; everything is enqueued on the batch's stream.  tetris_reset() on a split
  * batch applies the two-player winner rule.
  * Why three exchanges and not two: within one step the reference's order makes player 0's tick depend on player 1's loop-1
@@ -307,7 +311,8 @@ int tetris_split_stage_dev(tetris_batch *b, int stage, const uint8_t *d_rot, con
 /* One stage of a split-mode step of the built-in synthetic rollout (same policy and reset-seed schedule as
  * tetris_rollout_random, keyed by global game id and `step`; acting player = step mod 2): stage 0 draws the action on
  * the device, stage 2 counts and auto-resets finished games — identically on both sides, so no host round trip is
- * needed inside a rollout.  d_words / d_out as for tetris_split_stage_dev.                                          */
+ * needed inside a rollout; stage 3 = stage 2 of `step` + stage 0 of `step + 1`.  d_words / d_out as for
+ * tetris_split_stage_dev.                                                                                           */
 int tetris_split_rollout_stage_dev(tetris_batch *b, int stage, uint32_t policy_seed, uint64_t step, int ms,
                                    const uint32_t *const d_words[4], uint32_t *d_out);
 /* cumulative counters of the built-in rollouts of this batch: totals[4] = {env_steps, episodes, lines_cleared,

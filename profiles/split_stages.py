@@ -28,7 +28,8 @@ A, Bw = [z(), z()], [z(), z()]
 words = [B[s].split_words(A[s].data_ptr(), A[1 - s].data_ptr(), Bw[0].data_ptr(), Bw[1].data_ptr()) for s in (0, 1)]
 
 
-def step(k):
+def step3(k):
+    """three kernels per side and step (stages A, B, C): what a loop with host-side actions runs"""
     for s in (0, 1):
         B[s].split_rollout_stage(0, k, out=A[s].data_ptr())
     B[0].split_rollout_stage(1, k, words=words[0], out=Bw[0].data_ptr())
@@ -37,16 +38,41 @@ def step(k):
         B[s].split_rollout_stage(2, k, words=words[s])
 
 
+def step2(k):
+    """two kernels per side and step: stage B, then stage C fused with stage A of the next step (the device-driven rollout)"""
+    B[0].split_rollout_stage(1, k, words=words[0], out=Bw[0].data_ptr())
+    B[1].split_rollout_stage(1, k, words=words[1], out=Bw[1].data_ptr())
+    for s in (0, 1):
+        B[s].split_rollout_stage(3, k, words=words[s], out=A[s].data_ptr())
+
+
+def timed(fn, first, count):
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for k in range(first, first + count):
+        fn(k)
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / count
+
+
 for k in range(64):
-    step(k)
+    step3(k)
+us3 = timed(step3, 64, steps)
+k0 = 64 + steps
+for s in (0, 1):                                  # the fused form: one plain stage A up front ...
+    B[s].split_rollout_stage(0, k0, out=A[s].data_ptr())
+for k in range(k0, k0 + 64):
+    step2(k)
+us2 = timed(step2, k0 + 64, steps)
+k1 = k0 + 64 + steps
+B[0].split_rollout_stage(1, k1, words=words[0], out=Bw[0].data_ptr())      # ... and one plain stage C at the end
+B[1].split_rollout_stage(1, k1, words=words[1], out=Bw[1].data_ptr())
+for s in (0, 1):
+    B[s].split_rollout_stage(2, k1, words=words[s])
 torch.cuda.synchronize()
-e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-e0.record()
-for k in range(64, 64 + steps):
-    step(k)
-e1.record()
-torch.cuda.synchronize()
-us = e0.elapsed_time(e1) * 1e3 / steps
 t0, t1 = B[0].rollout_totals(), B[1].rollout_totals()
-print(json.dumps({"games_per_side": n, "steps": steps, "us_per_step_both_sides_one_gpu": us, "kernels_per_step": 6,
+print(json.dumps({"games_per_side": n, "steps": steps, "us_per_step_both_sides_one_gpu": us2, "kernels_per_step": 4,
+                  "us_per_step_both_sides_one_gpu_three_stage_form": us3, "kernels_per_step_three_stage_form": 6,
                   "env_steps_counted": int(t0[0]), "episodes": int(t0[1]), "lines": int(t0[2] + t1[2]), "sent": int(t0[3] + t1[3])}))

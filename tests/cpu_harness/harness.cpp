@@ -208,13 +208,14 @@ int tetris_create_split(tetris_batch** out, int n_games, int side, int height, i
 int tetris_set_stream(tetris_batch*, void*, int) { return TETRIS_OK; }
 static int split_stage_run(tetris_batch* b, int stage, KArgs& a, const uint32_t* const words[4], uint32_t* outw) {
     if (!b->split) return fail(TETRIS_E_ARG, "not a split batch");
-    if (stage < 0 || stage > 2) return fail(TETRIS_E_ARG, "stage");
+    if (stage < 0 || stage > 3) return fail(TETRIS_E_ARG, "stage");
     for (int k = 0; k < 4; k++) a.xw[k] = words ? words[k] : nullptr;
-    a.shadow = b->shadow.data(); a.xout = outw;
+    a.shadow = b->shadow.data(); a.xout = outw; a.split_side = b->side;
     for (int i = 0; i < b->N; i++) {
         if (stage == 0) split_body<0>(a, i, SHAPES.s);
         else if (stage == 1) split_body<1>(a, i, SHAPES.s);
-        else split_body<2>(a, i, SHAPES.s);
+        else if (stage == 2) split_body<2>(a, i, SHAPES.s);
+        else split_body<3>(a, i, SHAPES.s);
     }
     return TETRIS_OK;
 }

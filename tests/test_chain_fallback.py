@@ -38,9 +38,10 @@ def test_a_late_predecessor_makes_the_call_fall_back_and_the_results_stay_exact(
     total += c
     assert eng.take_errors() == 0 and eng.rollout_is_chained(1)
     eng.set_chain_spin_limit(2000)                         # ~1 ms
+    before = eng.rollout_totals()                          # (synchronises: nothing may drain the streams between the stall and the launches)
     eng.debug_stall(1, 30000)                              # the second launch of the next call (and every third after it) starts 30 ms late
-    c, _ = eng.rollout_random(50, 1, first_step=40)
-    total += c
+    eng.rollout_launch(50, 1, first_step=40)
+    total += eng.rollout_totals() - before
     assert eng.take_errors() == FELL_BACK
     assert eng.take_errors() == 0                          # reported once
     assert not eng.rollout_is_chained(1)                   # off until switched on again
@@ -67,9 +68,10 @@ def test_a_co_tenant_that_holds_most_wave_slots_costs_time_not_results():
     step = 0
     for rep in range(3):
         eng.set_chained(True)
+        before = eng.rollout_totals()
         eng.debug_stall(-1, 20000, 85)
-        c, _ = eng.rollout_random(64, 1, first_step=step)
-        total += c
+        eng.rollout_launch(64, 1, first_step=step)
+        total += eng.rollout_totals() - before
         step += 64
         assert eng.take_errors() in (0, FELL_BACK)
     _check(eng, ref, n, total, step)

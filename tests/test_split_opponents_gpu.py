@@ -33,7 +33,7 @@ class ThreadGather:
     def get_backend(self):
         return "nccl"            # device tensors, the batch on torch's stream
 
-    def all_gather_into_tensor(self, out, mine):
+    def all_gather_into_tensor(self, out, mine, group=None):
         import torch
         self.slots[self.local.rank] = mine.clone()
         torch.cuda.current_stream().synchronize()
