@@ -837,8 +837,7 @@ static bool chain_fits(tetris_batch* b) {
     }
     b->chain_depth = 0;
     // TETRIS_CHAIN_DEPTH=1..3 (measurement aid): at most that many launches in flight.  1 = the chained kernel on ONE stream: its
-    // dispatches are then serialised by the stream, which is what per-dispatch PMC counters need (the TCC counters are chip-wide
-    // and restart with every dispatch, so dispatches that overlap read parts of each other's traffic: profiles/pmc_summary.py).
+    // dispatches are then serialised by the stream — the reference point for per-dispatch PMC counters (profiles/pmc_summary.py).
     static const int cap = [] { const char* e = getenv("TETRIS_CHAIN_DEPTH"); const int v = e ? atoi(e) : CHAIN_STREAMS; return v < 1 ? 1 : (v > CHAIN_STREAMS ? CHAIN_STREAMS : v); }();
     for (int d = cap; d >= 1 && !b->chain_depth; d--)
         if (d * waves <= b->chain_capacity) b->chain_depth = d;

@@ -148,49 +148,151 @@ class coopintrinsic_reward(maingoal_reward):
 
 
 class _player_view:
-    """What the reference's pybind `State` exposes for one player (PythonHandle.h:54-82), as numpy
-    arrays decoded from a tetris_record."""
+    """What the reference's pybind `State` exposes for one player (PythonHandle.h:54-82), as numpy arrays."""
 
     __slots__ = ("field", "piece", "x", "y", "inc_lines", "combo_time", "combo_count", "nextpiece", "reward", "dead")
 
-    def __init__(self, rec, height, width):
-        self.field = rec["field"][:height, :width].copy()
-        self.piece = rec["grid"].copy()
-        self.x = np.array([rec["x"]], np.int8)
-        self.y = np.array([rec["y"]], np.int8)
-        self.inc_lines = np.array([rec["inc_count"]], np.uint8)
-        self.combo_time = np.array([rec["combo_remaining"]], np.uint16)
-        self.combo_count = np.array([rec["combo_count"]], np.uint8)
-        self.nextpiece = np.array([rec["next"]], np.uint8)
-        self.reward = np.array([rec["reward"]], np.uint8)
-        self.dead = np.array([rec["dead"]], np.uint8)
+
+# piece grids as State.piece shows them: SURVEY App. B row masks (rows y0..y3 as hex nibbles, bit x = column x) and the grid values
+# {4,3,5,7,2,1,6} of gamePlay.cpp:125-139; index [kind][current rotation]; kind 7 = no piece
+_SHAPE_ROWS = ((0x2260, 0x0710, 0x3220, 0x4700), (0x2230, 0x1700, 0x6220, 0x0740), (0x2640, 0x0630, 0x1320, 0x6300),
+               (0x2310, 0x3600, 0x4620, 0x0360), (0x2222, 0x0f00, 0x4444, 0x00f0), (0x0720, 0x2320, 0x2700, 0x2620),
+               (0x0660, 0x0660, 0x0660, 0x0660))
+_GRID_VALUE = (4, 3, 5, 7, 2, 1, 6)
+_GRIDS = np.zeros((8, 4, 4, 4), np.uint8)
+for _k in range(7):
+    for _r in range(4):
+        for _gy in range(4):
+            for _gx in range(4):
+                if (_SHAPE_ROWS[_k][_r] >> (4 * (3 - _gy) + _gx)) & 1:
+                    _GRIDS[_k, _r, _gy, _gx] = _GRID_VALUE[_k]
+
+
+class snapshot_batch:
+    """The games of ONE get_state() / simulate_actions() call as they came off the device in one call: snapshot words [n, words]
+    (csrc/tetris_layout.h; the exact state incl. RNG position, what tetris_restore takes back).  Everything the reference's
+    `State` views show (PythonHandle.h:54-82) is a pure function of these words and is decoded here, for all n games at once,
+    the first time any of it is looked at; a loop that only carries states along never pays for it."""
+
+    def __init__(self, blob, height, width, n_players):
+        self.blob = blob
+        self.height, self.width, self.n_players = int(height), int(width), int(n_players)
+        self.nw = (blob.shape[1] - layout.NGWORDS) // self.n_players
+        self._views = None
+
+    def __len__(self):
+        return len(self.blob)
+
+    def views(self):
+        if self._views is None:
+            P, H, nw = self.n_players, self.height, self.nw
+            boards = self.blob[:, layout.NGWORDS:].reshape(len(self.blob), P, nw)
+            rows = np.arange(H, dtype=np.uint32)[:, None]
+            bit = lambda cols: ((cols[:, :, None, :] >> rows) & np.uint32(1)).astype(np.uint8)        # [n,P,10] -> [n,P,H,10]
+            field = bit(boards[:, :, layout.W_COL0:layout.W_COL0 + layout.NCOL])
+            if nw > layout.NWORDS:                       # colour planes: cell value = 1 + 3-bit plane value on occupied squares
+                t0 = layout.NWORDS
+                value = 1 + bit(boards[:, :, t0:t0 + 10]) + 2 * bit(boards[:, :, t0 + 10:t0 + 20]) + 4 * bit(boards[:, :, t0 + 20:t0 + 30])
+                field = field * value
+            w, m, dc = boards[:, :, layout.W_PIECE], boards[:, :, layout.W_MISC], boards[:, :, layout.W_DROPCOMBO]
+            meta = self.blob[:, layout.G_META]
+            self._views = {
+                "field": field, "piece": _GRIDS[w & 7, (w >> 3) & 3],
+                "x": (((w >> 5) & 15).astype(np.int16) - 4).astype(np.int8), "y": ((w >> 9) & 31).astype(np.int8),
+                "nextpiece": ((w >> 14) & 7).astype(np.uint8), "dead": ((w >> 17) & 1).astype(np.uint8),
+                "reward": ((w >> 19) & 255).astype(np.uint8), "inc_lines": (m & 255).astype(np.uint8),
+                "combo_count": ((m >> 8) & 255).astype(np.uint8), "combo_time": (dc >> 16).astype(np.uint16),
+                "round_over": ((meta >> 16) & 1).astype(np.uint8), "last_winner": (((meta >> 17) & 15).astype(np.int16) - 1).astype(np.int8),
+            }
+        return self._views
 
 
 class backend_snapshot:
-    """Stand-in for the copied PythonHandle inside a reference `state`: `.states[p]` views plus the raw
-    snapshot words that restore the exact game (RNG position included) on the GPU."""
+    """Stand-in for the copied PythonHandle inside a reference `state`: `.states[p]` views plus the raw snapshot words that
+    restore the exact game (RNG position included) on the GPU.  A view into game `j` of a snapshot_batch; the words are copied
+    out of the batch, and the views decoded, when first asked for."""
 
-    def __init__(self, blob, records, height, width, round_over=0, last_winner=-1):
-        self.blob = np.array(blob, dtype=np.uint32, copy=True)
-        self.records = records
-        self.states = [_player_view(records[p], height, width) for p in range(len(records))]
-        self.round_over = int(round_over)
-        self.last_winner = int(last_winner)
-        self.height, self.width = height, width
+    def __init__(self, batch, j):
+        self._batch, self._j = batch, int(j)
+        self._blob = self._states = None
+        self.height, self.width = batch.height, batch.width
+
+    @classmethod
+    def from_blob(cls, blob, height, width, n_players):
+        """a standalone snapshot of one game from its words (unpickling, tests)"""
+        return cls(snapshot_batch(np.array(blob, dtype=np.uint32, copy=True).reshape(1, -1), height, width, n_players), 0)
+
+    @property
+    def blob(self):
+        if self._blob is None:
+            self._blob = self._batch.blob[self._j].copy()
+        return self._blob
+
+    @property
+    def states(self):
+        if self._states is None:
+            v, j = self._batch.views(), self._j
+            out = []
+            for p in range(self._batch.n_players):
+                s = _player_view()
+                s.field, s.piece = v["field"][j, p], v["piece"][j, p]
+                for name in ("x", "y", "inc_lines", "combo_time", "combo_count", "nextpiece", "reward"):
+                    setattr(s, name, v[name][j, p:p + 1])
+                s.dead = v["dead"][j, p:p + 1].copy()      # the one view Python writes (state.py:11,16): never shared
+                out.append(s)
+            self._states = out
+        return self._states
+
+    @property
+    def round_over(self):
+        return int((self._batch.blob[self._j, layout.G_META] >> 16) & 1)
+
+    @property
+    def last_winner(self):
+        return int((self._batch.blob[self._j, layout.G_META] >> 17) & 15) - 1
+
+    @property
+    def n_players(self):
+        return self._batch.n_players
+
+    @property
+    def records(self):
+        """per-player scalars beyond the State views (time_ms, draw counters), decoded from the words: a structured array [P]"""
+        b = self.blob[layout.NGWORDS:].reshape(self._batch.n_players, self._batch.nw)
+        rec = np.zeros(self._batch.n_players, dtype=[("time_ms", np.int32), ("piece_draws", np.uint32), ("hole_draws", np.uint32),
+                                                     ("dead", np.uint8), ("next", np.uint8), ("reward", np.uint8)])
+        rec["time_ms"] = b[:, layout.W_TIME].view(np.int32)
+        rec["piece_draws"], rec["hole_draws"] = b[:, layout.W_PIECE_DRAWS], b[:, layout.W_HOLE_DRAWS]
+        rec["dead"], rec["next"], rec["reward"] = (b[:, layout.W_PIECE] >> 17) & 1, (b[:, layout.W_PIECE] >> 14) & 7, (b[:, layout.W_PIECE] >> 19) & 255
+        return rec
+
+    def dead_flags(self):
+        if self._states is not None:
+            return [s.dead[0] for s in self._states]
+        nw, w = self._batch.nw, self._batch.blob[self._j]
+        return [np.uint8((w[layout.NGWORDS + p * nw + layout.W_PIECE] >> 17) & 1) for p in range(self._batch.n_players)]
 
     def copy(self):
-        b = backend_snapshot(self.blob, self.records.copy(), self.height, self.width, self.round_over, self.last_winner)
-        for mine, theirs in zip(b.states, self.states):
-            mine.dead[0] = theirs.dead[0]
+        b = backend_snapshot(self._batch, self._j)
+        if self._blob is not None:
+            b._blob = self._blob.copy()
+        if self._states is not None:
+            for mine, theirs in zip(b.states, self._states):
+                mine.dead[0] = theirs.dead[0]
         return b
 
     def sync_dead_to_blob(self):
         """Python may write `states[p].dead[0]` (state.py:11,16); carry it into the restore words."""
-        # words per player-board come from the blob itself: 39, or 69 for batches with colour planes (tetris_layout.h)
-        nw = (len(self.blob) - layout.NGWORDS) // len(self.states)
-        for p, s in enumerate(self.states):
+        if self._states is None:
+            return
+        nw = self._batch.nw          # words per player-board: 39, or 69 for batches with colour planes (tetris_layout.h)
+        for p, s in enumerate(self._states):
             w = layout.NGWORDS + p * nw + layout.W_PIECE
             self.blob[w] = (self.blob[w] & ~np.uint32(1 << 17)) | (np.uint32(1 << 17) if s.dead[0] else np.uint32(0))
+
+    def __reduce__(self):            # pickles as its own words (not as the batch it was cut from)
+        self.sync_dead_to_blob()
+        return (backend_snapshot.from_blob, (self.blob, self.height, self.width, self._batch.n_players))
 
 
 class state:
@@ -200,10 +302,34 @@ class state:
     def __init__(self, backend_state, state_processor, unlocked=True):
         self.state_processor = state_processor
         self.backend_state = backend_state.copy()
-        self.is_dead = [view.dead[0] for view in backend_state.states]
+        self.is_dead = self.backend_state.dead_flags()
         self.unlocked = True
         if not unlocked:
             self.lock()
+
+    @classmethod
+    def _of_batch(cls, batch, j, state_processor):
+        """game j of a snapshot_batch, without touching it (what get_state hands out)"""
+        s = cls.__new__(cls)
+        s.state_processor, s.unlocked = state_processor, True
+        s._pending = (batch, j)
+        return s
+
+    def __getattr__(self, name):     # only reached for attributes not set yet: the two lazy ones of _of_batch
+        if name in ("backend_state", "is_dead"):
+            pending = self.__dict__.pop("_pending", None)
+            if pending is not None:
+                self.backend_state = backend_snapshot(*pending)
+                self.is_dead = self.backend_state.dead_flags()
+                return self.__dict__[name]
+        raise AttributeError(name)
+
+    def __getstate__(self):
+        self.backend_state           # (materialise before pickling)
+        return self.__dict__
+
+    def __setstate__(self, d):
+        self.__dict__.update(d)
 
     def _write_dead(self, values):
         for view, value in zip(self.backend_state.states, values):
@@ -230,7 +356,70 @@ class state:
         return [self.state_processor(self.backend_state, p) for p in players]
 
     def __len__(self):
-        return len(self.backend_state.states)
+        return self.backend_state.n_players
 
     def __iter__(self):
         return iter(self.backend_state.states)
+
+
+class lazy_list(list):
+    """A list whose n elements are made by `make(j)` the first time ANY of them is looked at (or the list is changed): what
+    get_state returns for thousands of games — a worker loop that hands the states on (to an experience buffer, to the next
+    get_state) does not pay for n Python objects per call, code that indexes, iterates or pickles it sees an ordinary list."""
+
+    def __init__(self, n, make):
+        super().__init__()
+        self._n, self._make = int(n), make
+
+    def _fill(self):
+        make = self.__dict__.pop("_make", None)
+        if make is not None:
+            list.extend(self, [make(j) for j in range(self._n)])
+
+    def __len__(self):
+        return self._n if "_make" in self.__dict__ else list.__len__(self)
+
+    def __reduce_ex__(self, protocol):
+        self._fill()
+        return (list, (list(self),))
+
+    def __radd__(self, other):       # plain_list + lazy_list: list.__add__ would read this object's (still empty) storage directly
+        self._fill()
+        return list.__add__(other, self)
+
+
+def _filled(name):
+    def method(self, *args, **kwargs):
+        self._fill()
+        return getattr(list, name)(self, *args, **kwargs)
+    method.__name__ = name
+    return method
+
+
+for _name in ("__getitem__", "__iter__", "__contains__", "__reversed__", "__eq__", "__ne__", "__lt__", "__le__", "__gt__", "__ge__",
+              "__repr__", "__add__", "__mul__", "__rmul__", "__iadd__", "__imul__", "__setitem__", "__delitem__", "index", "count",
+              "copy", "append", "extend", "insert", "pop", "remove", "sort", "reverse", "clear"):
+    setattr(lazy_list, _name, _filled(_name))
+lazy_list.__hash__ = None
+
+
+class action_batch(lazy_list):
+    """n actions held as arrays (keys uint8 [n, K], lens uint8 [n]): what an agent that decides for all envs at once hands to
+    perform_action — the environment takes the arrays as they are instead of packing n Python lists; looked at as a list it
+    holds `action` objects like any other."""
+
+    def __init__(self, keys, lens):
+        self.keys = np.ascontiguousarray(keys, dtype=np.uint8)
+        self.lens = np.ascontiguousarray(lens, dtype=np.uint8)
+        assert self.keys.ndim == 2 and self.lens.shape == (len(self.keys),)
+        super().__init__(len(self.keys), lambda j: action(self.keys[j, : self.lens[j]].tolist()))
+
+    @classmethod
+    def from_rt(cls, rot, trans):
+        """SVENton's (rotation, translation) encoding [8]*r + [2] + [3]*t + [7] (sventon_utils.py:9-13) for n envs"""
+        rot, trans = np.asarray(rot, np.int64).reshape(-1), np.asarray(trans, np.int64).reshape(-1)
+        n, K = len(rot), int((rot + trans).max(initial=0)) + 2
+        col = np.arange(K)[None, :]
+        keys = np.where(col < rot[:, None], 8, np.where(col == rot[:, None], 2, np.where(col <= (rot + trans)[:, None], 3, 7)))
+        keys = np.where(col > (rot + trans + 1)[:, None], 0, keys)
+        return cls(keys.astype(np.uint8), (rot + trans + 2).astype(np.uint8))

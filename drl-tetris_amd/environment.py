@@ -21,7 +21,7 @@ import numpy as np
 
 from . import data_types, state_processors
 from .capi import TetrisBatch
-from .data_types import action, action_list, maingoal_reward, null_action, state
+from .data_types import action, action_batch, action_list, lazy_list, maingoal_reward, null_action, snapshot_batch, state
 
 DEFAULT_SETTINGS = {          # the env-relevant keys of experiments/presets.py:123-182
     "game_size": [22, 10],
@@ -81,12 +81,14 @@ class tetris_environment_vector:
         self.backend = TetrisBatch(n_envs, self.n_players, self.height, self.width, pieces=s["pieces"], seeds=seed,
                                    device=s["device"], lib_path=_lib_path, colours=s["field_colours"])
         self._env_ids = list(range(n_envs))
+        self._all_idx = np.arange(n_envs, dtype=np.int32)
         self._shared_zero = self._zero_reward()
         self.done = np.zeros(n_envs, bool)
         self.rounds_played = np.zeros(n_envs, np.int64)
         self.round_reward = [[self._zero_reward() for _ in self.player_idxs] for _ in range(n_envs)]
         self.tot_reward = [[self._zero_reward() for _ in self.player_idxs] for _ in range(n_envs)]
-        self.last_reward = [[None for _ in self.player_idxs] for _ in range(n_envs)]
+        self._last_reward = [[None for _ in self.player_idxs] for _ in range(n_envs)]
+        self._last_pending = None
         if init_envs is None or (type(init_envs) is list and all(e is None for e in init_envs)):
             self.reset()                       # "upon agreement with backend, we always reset once" (tetris_environment.py:40-41)
         else:
@@ -97,10 +99,37 @@ class tetris_environment_vector:
         return maingoal_reward([0])
 
     def _idx(self, env):
+        if env is None:
+            return self._all_idx
         return np.asarray(parse_arg(env, self._env_ids), dtype=np.int32)
 
     def _players(self, player, n):
         return [int(p) for p in parse_arg(player, self.player_idxs, fill_up=n)]
+
+    def _who(self, player, n):
+        """the acting player of each of n envs as an array (parse_arg conventions: None = every player index in turn — which,
+        like the reference, only makes sense when n == n_players —, int = the same for all, list = one per env)"""
+        if isinstance(player, (int, np.integer)):
+            assert 0 <= player < self.n_players
+            return np.full(n, int(player), np.int64)
+        return np.asarray(self._players(player, n), np.int64)
+
+    def _states_of(self, blob):
+        batch = snapshot_batch(blob, self.height, self.width, self.n_players)
+        processor = self.state_processor
+        states = lazy_list(len(blob), lambda j: state._of_batch(batch, j, processor))
+        states._batch = batch
+        return states
+
+    @property
+    def last_reward(self):
+        """reward object of each env's last perform_action, per player (written back lazily: one Python loop per LOOK, not per step)"""
+        pending, self._last_pending = self._last_pending, None
+        if pending is not None:
+            idx, who, rewards = pending
+            for j in range(len(idx)):
+                self._last_reward[idx[j]][who[j]] = rewards[j]
+        return self._last_reward
 
     def _reward(self, done, dead, player):
         """tetris_environment.reward_fcn (tetris_environment.py:135-149)"""
@@ -113,19 +142,28 @@ class tetris_environment_vector:
                 base = -1
         return base
 
-    def _pack(self, actions, players, n):
-        for a in actions:
-            assert type(a) is action, f"perform_action(action a, int p) was called with type(action)={type(a)}"
-        length = np.fromiter(map(len, actions), np.int64, n)
-        assert int(length.max(initial=0)) <= 255, "an action may hold at most 255 keys (uint8 length on the device)"
-        total = int(length.sum())
-        keys = np.zeros((n, self.n_players, max(1, int(length.max(initial=0)))), np.uint8)
-        lens = np.ones((n, self.n_players), np.uint8)          # the other players get the null action [0]
-        who = np.asarray(players, np.int64)
-        rows = np.repeat(np.arange(n), length)
-        cols = np.arange(total) - np.repeat(np.cumsum(length) - length, length)
-        keys[rows, who[rows], cols] = np.fromiter(itertools.chain.from_iterable(actions), np.uint8, total)
-        lens[np.arange(n), who] = length
+    def _pack(self, actions, who, n):
+        """n actions (Python `action` lists, or an action_batch that already holds them as arrays) of the players `who` ->
+        keys uint8 [n, P, K], lens uint8 [n, P]; every other player gets the null action [0] (tetris_environment.py:106-108)"""
+        who = np.asarray(who, np.int64)
+        lens = np.ones((n, self.n_players), np.uint8)
+        rows = np.arange(n)
+        if isinstance(actions, action_batch) and "_make" in actions.__dict__:      # (a batch that was looked at is a plain list now)
+            assert len(actions) == n
+            keys = np.zeros((n, self.n_players, max(1, actions.keys.shape[1])), np.uint8)
+            keys[rows, who] = actions.keys
+            lens[rows, who] = actions.lens
+            return keys, lens
+        assert set(map(type, actions)) <= {action}, "perform_action(action a, int p) was called with an action that is not of type `action`"
+        packed = list(map(bytes, actions))          # (a key outside 0..255 raises here)
+        length = np.fromiter(map(len, packed), np.int64, n)
+        width = int(length.max(initial=0))
+        assert width <= 255, "an action may hold at most 255 keys (uint8 length on the device)"
+        keys = np.zeros((n, self.n_players, max(1, width)), np.uint8)
+        flat = np.frombuffer(b"".join(packed), np.uint8)
+        r = np.repeat(rows, length)
+        keys[r, who[r], np.arange(len(flat)) - np.repeat(np.cumsum(length) - length, length)] = flat
+        lens[rows, who] = length
         return keys, lens
 
     # ------------------------------------------------------------------ env interface
@@ -143,14 +181,15 @@ class tetris_environment_vector:
     def perform_action(self, actions, env=None, player=None):
         idx = self._idx(env)
         n = len(idx)
-        players = self._players(player, n)
-        actions = list(actions)
-        assert len(actions) == n and len(players) == n
-        keys, lens = self._pack(actions, players, n)
-        done, _lines, dead = self.backend.step_keys(keys, lens, ms=self.settings["time_elapsed_each_action"], idx=idx)
+        who = self._who(player, n)
+        if not isinstance(actions, action_batch):
+            actions = list(actions)
+        assert len(actions) == n and len(who) == n
+        keys, lens = self._pack(actions, who, n)
+        done, _lines, dead = self.backend.step_keys(keys, lens, ms=self.settings["time_elapsed_each_action"], idx=None if env is None else idx)
         # reward_fcn (tetris_environment.py:135-149) is 0 unless the round just ended: only those envs get a reward object of
         # their own and an update of the running sums (x + 0 leaves the sums as they are); the others share one zero reward
-        # (reward objects are never modified in place: `+` / `-` return new ones).  At 8k envs this is 20x less Python time.
+        # (reward objects are never modified in place: `+` / `-` return new ones).  Nothing below loops over all n envs.
         done_b = done.astype(bool)
         self.done[idx] = done_b
         zero = self._shared_zero
@@ -158,32 +197,30 @@ class tetris_environment_vector:
         if self.settings["extra_rewards"]:
             # tetris_environment.py:144-149: two components, [w_base * win/lose signal, w_combo * my combo count], every step
             w_base, w_combo = self.settings["reward_ammount"]
-            combo = self.backend.observe_packed(idx, np.asarray(players, np.uint8))[1][0][:, 4]
+            combo = self.backend.observe_packed(None if env is None else idx, who.astype(np.uint8))[1][0][:, 4]
             for j in range(n):
-                i, p = idx[j], players[j]
+                i, p = idx[j], int(who[j])
                 r = maingoal_reward([w_base * self._reward(bool(done_b[j]), dead[j], p), w_combo * int(combo[j])])
                 rewards[j] = r
                 self.round_reward[i][p] = self.round_reward[i][p] + r
                 self.tot_reward[i][p] = self.tot_reward[i][p] + r
         for j in (() if self.settings["extra_rewards"] else np.nonzero(done_b)[0]):
-            i, p = idx[j], players[j]
+            i, p = idx[j], int(who[j])
             base = self._reward(True, dead[j], p)
             if base != 0:
                 r = maingoal_reward([base])
                 rewards[j] = r
                 self.round_reward[i][p] = self.round_reward[i][p] + r
                 self.tot_reward[i][p] = self.tot_reward[i][p] + r
-        last = self.last_reward
-        for j in range(n):
-            last[idx[j]][players[j]] = rewards[j]
+        self.last_reward                              # (apply what an earlier call left pending, then leave this call's)
+        self._last_pending = (idx, who, rewards)
         return rewards, done_b.tolist()
 
     def get_state(self, env=None):
-        idx = self._idx(env)
-        blobs = self.backend.snapshot(idx)
-        rec, ro, lw = self.backend.observe(idx)
-        return [state(data_types.backend_snapshot(blobs[j], rec[j], self.height, self.width, ro[j], lw[j]), self.state_processor)
-                for j in range(len(idx))]
+        """One `state` per env (data_types/state.py:1-40), cut from ONE snapshot of the listed games: a single kernel and a single
+        copy for all of them; the Python objects and the State views are made when they are first looked at (data_types.lazy_list,
+        snapshot_batch)."""
+        return self._states_of(self.backend.snapshot(None if env is None else self._idx(env)))
 
     def set(self, target, env=None):
         """Restore games from state / backend_snapshot / another vector env (tetris_environment.py:168-176)."""
@@ -192,7 +229,12 @@ class tetris_environment_vector:
             src = target.backend.snapshot(np.arange(len(idx), dtype=np.int32) if env is None else idx)
             self.backend.restore(src, idx)
             return [None for _ in idx]
-        targets = target if type(target) is list else [target for _ in idx]
+        if isinstance(target, lazy_list) and "_make" in target.__dict__ and getattr(target, "_batch", None) is not None and len(target) == len(idx):
+            batch = target._batch                        # states nobody has looked at: their words go back as they came
+            self.backend.restore(batch.blob, idx)
+            self.done[idx] = ((batch.blob[:, data_types.layout.G_META] >> 16) & 1).astype(bool)
+            return [None for _ in idx]
+        targets = target if isinstance(target, list) else [target for _ in idx]
         blobs = np.zeros((len(idx), self.backend.snapshot_words), np.uint32)
         for j, t in enumerate(targets):
             b = t.backend_state if isinstance(t, state) else t
@@ -219,19 +261,17 @@ class tetris_environment_vector:
                               device=self.settings["device"], lib_path=self._lib_path, colours=self.settings["field_colours"])
         scratch.restore(np.repeat(anchors, counts, axis=0))
         flat_actions = [a if type(a) is action else action(a) for al in actions for a in al]
-        flat_players = [p for p, c in zip(players, counts) for _ in range(c)]
+        flat_players = np.repeat(np.asarray(players, np.int64), counts)
         keys, lens = self._pack(flat_actions, flat_players, total)
         if finalize:
             scratch.step_keys(keys, lens, ms=self.settings["time_elapsed_each_action"])
         else:
             scratch.make_actions(keys, lens)
-        blobs = scratch.snapshot()
-        rec, ro, lw = scratch.observe()
+        batch = snapshot_batch(scratch.snapshot(), self.height, self.width, self.n_players)
         scratch.close()
         out, k = [], 0
         for c in counts:
-            out.append([state(data_types.backend_snapshot(blobs[k + j], rec[k + j], self.height, self.width, ro[k + j], lw[k + j]),
-                              self.state_processor) for j in range(c)])
+            out.append([state._of_batch(batch, k + j, self.state_processor) for j in range(c)])
             k += c
         return out
 
@@ -266,7 +306,8 @@ class tetris_environment_vector:
     def get_info(self, env=None):
         idx = self._idx(env)
         rec, _, _ = self.backend.observe(idx)
-        return [{"is_dead": [rec[j, p]["dead"] for p in self.player_idxs], "reward": self.last_reward[i],
+        last = self.last_reward
+        return [{"is_dead": [rec[j, p]["dead"] for p in self.player_idxs], "reward": last[i],
                  "tot_reward": self.tot_reward[i], "round_reward": self.round_reward[i],
                  "rounds_played": int(self.rounds_played[i])} for j, i in enumerate(idx)]
 
@@ -289,6 +330,7 @@ class tetris_environment_vector:
         """Everything but the device handle: settings, reward bookkeeping and the games as snapshot words.  Unlike the
         reference's pickle (PythonHandle.h:180-182 drops the generators) the RNG positions survive.  A `seed_source` that
         cannot be pickled (a lambda) is replaced by the default wall-clock source on load."""
+        self.last_reward                              # (nothing pending in the pickle)
         d = {k: v for k, v in self.__dict__.items() if k not in ("backend", "state_processor", "_seed_source")}
         d["settings"] = dict(self.settings)
         try:

@@ -11,7 +11,7 @@ The read figure is multiplied by a factor CALIBRATED in the same GPU call on zer
 known exactly (MI355X_MICROARCH.md, HBM: on gfx950 FETCH_SIZE reports half the bytes of a coalesced streaming read; other access
 widths must be calibrated on a known byte count): factor = known read bytes / read figure of the calibration run.
 The write figure must not be below what the kernel provably stores (stored words x 4 B x games): the script REFUSES such a
-summary (exit 1) — that is how a run whose dispatches overlapped shows itself (counters are chip-wide and restart per dispatch).
+summary (exit 1).
 Infinity-Cache hits are inside these fabric-side counters (the 10 MB state of 64k boards is resident there): HBM proper sees less."""
 import json
 import sys
@@ -65,7 +65,7 @@ res = {
 if overlapped:
     oname, ok = pick(json.load(open(overlapped)), "k_chain" if P == 1 else "k_duo")
     res["overlapped_run_for_comparison"] = {
-        "kernel": oname, "source": overlapped, "note": "three chain streams: dispatches overlap, chip-wide counters restart per dispatch — NOT used",
+        "kernel": oname, "source": overlapped, "note": "the same command on three chain streams (the default): rocprofv3 serialises the dispatches of a --pmc run, so the counters agree with the one-stream run",
         "counters": {c[:-7]: {s: v[s] for s in ("n", "min", "median", "max", "mean")} for c, v in ok.items() if c.endswith("__stats") and c.startswith("TCC")}}
 if write < floor:
     json.dump(res, open(out + ".refused", "w"), indent=1)

@@ -1,11 +1,13 @@
 #!/usr/bin/env python3
 """Per-kernel, per-counter statistics of rocprofv3 --pmc counter_collection CSVs -> <dir>/summary.json (+ printed).
 
-Every dispatch is kept as a sample: n, mean, min, median, max per (kernel, counter).  A mean alone hid round 2's defect: chained
-launches overlap on three streams, the TCC counters are chip-wide and are restarted per dispatch, so a dispatch that overlaps
-another one reads a part of its own traffic (WRITE_SIZE 4 516 KiB for a kernel that stores 7 168 KiB).  Traffic figures are
-therefore taken from runs whose dispatches are serialised (TETRIS_CHAIN_DEPTH=1 or TETRIS_NO_CHAIN=1) and the spread of the
-overlapped run is shown beside them.  Raw counters only; byte figures are derived in make_traffic_json.py."""
+Every dispatch is kept as a sample: n, mean, min, median, max per (kernel, counter).  Round 2 kept the mean alone, over 2 128
+dispatches of one process (device pre-conditioning, warm-up, timed launches and pre-queued groups behind a blocker kernel), and
+that mean was wrong (WRITE_SIZE 4 516 KiB for a kernel that provably stores 7 168 KiB) without anything in the file showing it.
+Round 3's runs hold the warm-up and the timed launches only (bench.py --precondition-ms 0 --no-gpu-paced), the spread is printed,
+and the traffic figure is cross-checked three ways: the chained kernel on one stream (TETRIS_CHAIN_DEPTH=1), on three streams,
+and the un-chained kernel — rocprofv3 serialises the dispatches of a --pmc run, and the three agree (profiles/r03/).
+Raw counters only; byte figures are derived in make_traffic_json.py."""
 import csv
 import glob
 import json

@@ -74,6 +74,7 @@ def test_c4_enumerate_16384_boards_at_step_12():
     d_clr = torch.zeros(n * 40, dtype=torch.uint8, device=dev)
     d_after = torch.zeros(n * 40 * 10, dtype=torch.int32, device=dev)
     p = lambda t: C.c_void_p(t.data_ptr())
+    torch.cuda.synchronize()           # the fills above run on torch's stream, the kernel below on the batch's own
     eng._check(eng.lib.tetris_enumerate_drops_dev(eng._h, None, n, None, p(d_valid), p(d_land), p(d_clr), p(d_after)))
     eng.sync()
     assert np.array_equal(d_valid.cpu().numpy().reshape(n, 4, 10), v2)
@@ -83,6 +84,7 @@ def test_c4_enumerate_16384_boards_at_step_12():
     # ... and its planar form (rotation-minor column planes: [n][10][4] and [10][n][10][4])
     for t in (d_valid, d_land, d_clr, d_after):
         t.zero_()
+    torch.cuda.synchronize()
     eng.enumerate_drops_dev(n, p(d_valid), p(d_land), p(d_clr), p(d_after), planar=True)
     eng.sync()
     assert np.array_equal(d_valid.cpu().numpy().reshape(n, 10, 4).transpose(0, 2, 1), v2)
