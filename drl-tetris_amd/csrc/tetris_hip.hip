@@ -200,7 +200,7 @@ __device__ __forceinline__ void observe_emit(const KArgs& a, const Game<P>& g, i
 // OBS (tetris_step_rt_observe_dev): after the step every lane turns its own board into the packed observation — slot 0 if its
 // player is the one the game's next decision is for, slot 1 otherwise; rows 0..31 / 32..63 of the wave's LDS tile.
 template <int MODE, bool CHAIN = false, bool OBS = false>
-__global__ __launch_bounds__(256) void k_duo(KArgs a) {
+__global__ __launch_bounds__(CHAIN ? 64 : 256, CHAIN ? 5 : 1) void k_duo(KArgs a) {
     __shared__ __attribute__((aligned(16))) uint32_t s_shapes_all[4][SHAPE_WORDS];      // per-wave copy, no block barrier (see k_game)
     extern __shared__ __attribute__((aligned(16))) uint32_t s_duo_tile[];               // OBS: 4 waves x 64 rows x nw words
     uint32_t* s_shapes = s_shapes_all[threadIdx.x >> 6];
@@ -239,18 +239,17 @@ __global__ __launch_bounds__(256) void k_duo(KArgs a) {
     Ctx cx = make_ctx(a, s_shapes, false);
     uint32_t my_lines = 0, my_sent = 0;
     int done = 0, out_reward = 0, out_dead = 0;
-    const int n_steps = ROLL ? a.steps : 1;
-    for (int s = 0; s < n_steps; s++) {
+    // ONE env-step per launch (launch_game sends fused rollouts to k_game<2>): as a loop over a.steps this kernel needed 199
+    // registers per lane instead of ~130 — everything stayed live around the loop's back edge.
+    {
         int r = 0, t = 0, acting = 0;
         ResetPrefetch rpf;
         rpf.ok = 0; rpf.seed16 = 0; rpf.word = 0;
         uint32_t sent_start = 0;
-        Player pre;
         uint32_t wa = 0;
         if (active) {
             if (ROLL) {
-                const unsigned long long step = a.first_step + (unsigned long long)s;
-                r = (int)(g.draw0 & 3u); t = (int)(g.draw1 % 10u); acting = (int)(step % 2ull);
+                r = (int)(g.draw0 & 3u); t = (int)(g.draw1 % 10u); acting = (int)(a.first_step % 2ull);
             } else {
                 r = (int)(g.draw0 & 3u); t = (int)(g.draw1 & 0xFFu); acting = (int)(g.draw1 >> 8);
             }
@@ -259,13 +258,24 @@ __global__ __launch_bounds__(256) void k_duo(KArgs a) {
             sent_start = q.lines_sent;
             // stage A
             if (!g.round_over && !q.dead && acting == side) play_rt(cx, q, r, t);
-            if (side == 1) pre = q;                              // rollback copy of the speculating player
             wa = split_settle(cx, g);
         }
         const uint32_t opp_a = __shfl_xor(wa, 32);
         uint32_t wb0 = 0, wb1 = 0;
         if (active) {
-            if (side == 1 && (opp_a & XW_DIED)) { q = pre; wa = 0; }   // player 0 died in loop 1: player 1 did not run (:153-156)
+            if (side == 1 && (opp_a & XW_DIED)) {
+                // Player 0 died in loop 1, so player 1 did not run it (PythonHandle.cpp:153-156): back to the board as it was after
+                // the key interpreter.  No copy of it is kept in registers (it cost ~40 of them in every lane of every step for a
+                // case that comes up once per episode at most): the launch has not stored anything yet, so the state before this
+                // step is still in memory — load it again and replay the keys.
+                const uint32_t keep = g.status;
+                load_player(br.s, br.o, br.ws, q, false, true, MEM);
+                prefetch_next(cx, q, g.seed16, g.status);
+                if (!g.round_over && !q.dead && acting == side) play_rt(cx, q, r, t);
+                sent_start = q.lines_sent;
+                g.status |= keep;
+                wa = 0;
+            }
             if (side == 0) {                                           // stage B0
                 const int in = (!(wa & XW_DIED) && (opp_a & XW_RAN) && !(opp_a & XW_DIED)) ? xw_sent(opp_a) : 0;
                 wb0 = split_tick(cx, g, a.ms, in);
@@ -293,7 +303,6 @@ __global__ __launch_bounds__(256) void k_duo(KArgs a) {
                 g.episode++;
                 reset_split(cx, g, episode_seed(a.game_offset + (uint32_t)gi, g.episode));
             }
-            if (ROLL && s + 1 < n_steps) policy_draw(a, (uint32_t)gi, a.first_step + (unsigned long long)s + 1ull, g.draw0, g.draw1);
         }
     }
     const uint32_t opp_lines = __shfl_xor(my_lines, 32), opp_sent = __shfl_xor(my_sent, 32);

@@ -136,9 +136,12 @@ def test_chained_launches_bit_exact_and_only_where_the_launches_in_flight_fit():
     assert total.tolist() == want.tolist()
     for lo in range(0, n, 8192):
         engines.assert_same_state(eng, ref, idx=np.arange(lo, lo + 8192, dtype=np.int32), where=f"games {lo}..")
-    # two-player boards: three launches of 64k games (2048 waves each) do not fit on the device together -> not chained; 8k games do
+    # two-player boards (k_duo, 32 games per wave): 64k games are 2048 waves per launch; two such launches fit on the device
+    # together (the chained kernel is held to 96 registers per lane: 5 waves per SIMD), so they chain over two streams — the
+    # full-size rollout against the oracle is test_64k_boards_rollout_bit_exact[2-96]; fused launches never chain for two players
     big = engines.make("hip", n, 2, seeds=seeds)
-    assert not big.rollout_is_chained(1)
+    assert big.rollout_is_chained(1) and not big.rollout_is_chained(4)
+    big.close()
     m = 8192
     small, sref = engines.make("hip", m, 2, seeds=seeds[:m]), engines.make("oracle", m, 2, seeds=seeds[:m])
     assert small.rollout_is_chained(1) and not small.rollout_is_chained(4)
