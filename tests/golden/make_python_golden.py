@@ -128,10 +128,13 @@ def dump_state_dicts(states, n_players, augment):
 
 
 def scenario(name, n_envs, n_players, game_size, steps, policy, augment=False, pieces=(0, 1, 2, 3, 4, 5, 6), extra_rewards=False,
-             simulate_every=0, seed0=4000):
+             simulate_every=0, seed0=4000, sd_every=1, actions_every=1, bar_null_moves=True, roundtrip_at=()):
+    """sd_every / actions_every: record state_dicts (+ unpacker batches) / action lists only every so many steps (0 = never; the
+    'actions' policy needs the lists every step).  roundtrip_at: steps at which set / copy round trips are recorded (below)."""
     vec_cls, env_cls, data_types, unpacker, set_time = import_reference()
     settings = {"presets": ["default"], "game_size": list(game_size), "n_players": n_players, "pieces": list(pieces), "render": False,
-                "augment_data": augment, "extra_rewards": extra_rewards, "reward_ammount": (1.0, 0.25)}
+                "augment_data": augment, "extra_rewards": extra_rewards, "reward_ammount": (1.0, 0.25), "bar_null_moves": bar_null_moves}
+    assert policy == "rt" or actions_every == 1
     rng = np.random.default_rng(seed0)
     clock = seed0
     set_time(clock)                                       # every env: constructor seed, then the "always reset once" seed
@@ -145,11 +148,47 @@ def scenario(name, n_envs, n_players, game_size, steps, policy, augment=False, p
         if n_players == 2:
             current = 1 - current                         # worker.py:96
         states = vec.get_state()
-        sd, m = dump_state_dicts(states, n_players, augment)
-        meta.update(m)
-        for k, v in sd.items():
-            rec["sd_" + k].append(v)
-        if n_players == 2:
+        if it in roundtrip_at:
+            # --- set / copy round trips (tetris_environment.py:162-176, tetris_environment_vector.py:116-120; state.py:5):
+            # (1) a step from the saved states, vector.set(list of states), the SAME step again: a state carries the whole game
+            #     (piece generators included), so both runs must give the same rewards, dones and boards;
+            acts_rt = [data_types.action([8] * int(rng.integers(0, 4)) + [2] + [3] * int(rng.integers(0, 10)) + [7]) for _ in range(n_envs)]
+            pk, pl, _ = pad_lists([list(a) for a in acts_rt], max_lists=n_envs)
+            rec["rt_keys"].append(pk); rec["rt_lens"].append(pl)
+            for run in (0, 1):
+                _, d = vec.perform_action(acts_rt, player=[int(p) for p in current])
+                after = vec.get_state()
+                sd_after, _m = dump_state_dicts(after, n_players, augment)
+                rec[f"rt_done_{run}"].append(np.array([bool(x) for x in d]))
+                for k, v in sd_after.items():
+                    rec[f"rt_sd{run}_" + k].append(v)
+                vec.set(states)                                   # list form: one saved state per env
+            # (2) ONE state broadcast to several envs: vector.set(state, env=[...]) — envs 1 and 2 become copies of env 0;
+            #     then everything is put back
+            vec.set(states[0], env=[1, 2])
+            sd_b, _m = dump_state_dicts(vec.get_state(), n_players, augment)
+            for k, v in sd_b.items():
+                rec["rt_bcast_" + k].append(v)
+            vec.set(states)
+            # (3) tetris_environment.copy(): an independent env that continues like the original would (stepped with simulate=True:
+            #     a copy has no reward bookkeeping — round_reward is None — and a plain perform_action raises on it)
+            twin = vec.envs[3].copy()
+            r_t, d_t = twin.perform_action(acts_rt[3], player=int(current[3]), simulate=True)
+            assert r_t is None
+            sd_t, _m = dump_state_dicts([twin.get_state()], n_players, augment)
+            rec["rt_copy_done"].append(bool(d_t))
+            for k, v in sd_t.items():
+                rec["rt_copy_" + k].append(v)
+            rec["rt_step"].append(it)
+            states = vec.get_state()
+        take_sd = sd_every and it % sd_every == 0
+        if take_sd:
+            sd, m = dump_state_dicts(states, n_players, augment)
+            meta.update(m)
+            for k, v in sd.items():
+                rec["sd_" + k].append(v)
+            rec["sd_step"].append(it)
+        if n_players == 2 and take_sd:
             if unp is None:
                 unp = unpacker(states[0], observation_mode="separate", player_mode="separate", separate_piece=True)
             vector, visual, piece = unp(states, [int(p) for p in current])
@@ -158,9 +197,11 @@ def scenario(name, n_envs, n_players, game_size, steps, policy, augment=False, p
                 rec[f"unp_visual{sl}"].append(np.asarray(visual[sl]))
                 rec[f"unp_piece{sl}"].append(np.asarray(piece[sl]))
         # the action lists of every env for its acting player (single-env API: the vector's get_actions is broken)
-        lists = [vec.envs[i].get_actions(states[i], player=int(current[i])) for i in range(n_envs)]
-        ak, al, an = zip(*[pad_lists([list(a) for a in L]) for L in lists])
-        rec["al_keys"].append(np.stack(ak)); rec["al_lens"].append(np.stack(al)); rec["al_n"].append(np.array(an))
+        if actions_every and it % actions_every == 0:
+            lists = [vec.envs[i].get_actions(states[i], player=int(current[i])) for i in range(n_envs)]
+            ak, al, an = zip(*[pad_lists([list(a) for a in L]) for L in lists])
+            rec["al_keys"].append(np.stack(ak)); rec["al_lens"].append(np.stack(al)); rec["al_n"].append(np.array(an))
+            rec["al_step"].append(it)
         if simulate_every and it % simulate_every == 0:
             for fin in (True, False):
                 sims = vec.envs[0].simulate_all_actions(states[0], player=int(current[0]), finalize=fin)
@@ -190,15 +231,21 @@ def scenario(name, n_envs, n_players, game_size, steps, policy, augment=False, p
             assert type(r).__name__ == "maingoal_reward"
         rec["reward_ext"].append(ext)
         rec["done"].append(np.array([bool(d) for d in dones]))
+        rec["dead"].append(np.array([[int(e.backend.states[p].dead[0]) for p in range(n_players)] for e in vec.envs], np.uint8))
+        info = [e.get_info() for e in vec.envs]
+        rec["info_rounds_played"].append(np.array([i_["rounds_played"] for i_ in info]))
+        rec["info_round_reward"].append(np.array([[float(r()) for r in i_["round_reward"]] for i_ in info]))
+        rec["info_tot_reward"].append(np.array([[float(r()) for r in i_["tot_reward"]] for i_ in info]))
         idx = [i for i, d in enumerate(dones) if d]       # worker.py:157-160
         clock += 1
         rec["reset_seed"].append(clock)
         if idx:
             set_time(clock)
             vec.reset(env=idx)
+        rec["last_winner"].append(np.array([int(e.backend.last_winner) for e in vec.envs], np.int8))     # PythonHandle.cpp:49-66, after the resets
     out = {k: np.stack(v) if isinstance(v[0], np.ndarray) else np.array(v) for k, v in rec.items()}
     out.update(dict(name=name, n_envs=n_envs, n_players=n_players, game_size=np.array(game_size), pieces=np.array(pieces), steps=len(rec["done"]),
-                    policy=policy, augment=augment, extra_rewards=extra_rewards, seed0=seed0, raised=raised,
+                    policy=policy, augment=augment, extra_rewards=extra_rewards, seed0=seed0, raised=raised, bar_null_moves=bar_null_moves,
                     meta_keys=np.array(sorted(meta)), meta_dtypes=np.array([meta[k][0] for k in sorted(meta)]),
                     meta_shapes=np.array([str(meta[k][1]) for k in sorted(meta)])))
     path = os.path.join(HERE, f"pygolden_{name}.npz")
@@ -211,3 +258,8 @@ if __name__ == "__main__":
     scenario("worker_2p_actions_aug", n_envs=4, n_players=2, game_size=(20, 10), steps=90, policy="actions", augment=True, simulate_every=15, seed0=7000)
     scenario("worker_2p_extra_rewards", n_envs=4, n_players=2, game_size=(20, 10), steps=60, policy="actions", extra_rewards=True, pieces=(6, 4), seed0=9000)
     scenario("worker_1p_rt", n_envs=3, n_players=1, game_size=(20, 10), steps=60, policy="rt", seed0=11000)
+    # round 3: a long two-player run at BASELINE's geometry with hundreds of finished rounds (winner bookkeeping after every
+    # reset), set / copy round trips; and action lists with the null move kept
+    scenario("big_2p_rt_20x10", n_envs=64, n_players=2, game_size=(20, 10), steps=400, policy="rt", seed0=13000, sd_every=16,
+             actions_every=0, roundtrip_at=(50, 233))
+    scenario("worker_2p_null_moves_kept", n_envs=4, n_players=2, game_size=(20, 10), steps=70, policy="actions", bar_null_moves=False, seed0=15000)
