@@ -48,6 +48,7 @@ template <int P>
 __global__ __launch_bounds__(64) void k_chain(KArgs a) {
     __shared__ __attribute__((aligned(16))) uint32_t s_shapes[SHAPE_WORDS];
     const int lane = threadIdx.x, wave = blockIdx.x;
+    if (a.steps < 0) { chain_census(a, lane == 0); return; }
     const int i = wave * CHAIN_LANES + lane;
     const bool active = lane < CHAIN_LANES && i < a.n;
     LaneCounters cnt = {0, 0, 0, 0};
@@ -200,7 +201,7 @@ __device__ __forceinline__ void observe_emit(const KArgs& a, const Game<P>& g, i
 // OBS (tetris_step_rt_observe_dev): after the step every lane turns its own board into the packed observation — slot 0 if its
 // player is the one the game's next decision is for, slot 1 otherwise; rows 0..31 / 32..63 of the wave's LDS tile.
 template <int MODE, bool CHAIN = false, bool OBS = false>
-__global__ __launch_bounds__(CHAIN ? 64 : 256, CHAIN ? 5 : 1) void k_duo(KArgs a) {
+__global__ __launch_bounds__(CHAIN ? 64 : 256) void k_duo(KArgs a) {
     __shared__ __attribute__((aligned(16))) uint32_t s_shapes_all[4][SHAPE_WORDS];      // per-wave copy, no block barrier (see k_game)
     extern __shared__ __attribute__((aligned(16))) uint32_t s_duo_tile[];               // OBS: 4 waves x 64 rows x nw words
     uint32_t* s_shapes = s_shapes_all[threadIdx.x >> 6];
@@ -211,6 +212,7 @@ __global__ __launch_bounds__(CHAIN ? 64 : 256, CHAIN ? 5 : 1) void k_duo(KArgs a
     const bool active = gi < a.n;
     constexpr bool ROLL = MODE == M_ROLLOUT, AUTO = MODE == M_STEP_RT_AUTO;
     constexpr int MEM = CHAIN ? MEM_AGENT : MEM_STREAM;
+    if (CHAIN && a.steps < 0) { chain_census(a, lane == 0); return; }
     Geo geo = geo_of(a);
     geo.P = 2;                           // compile-time stride factor for the hot loads
     const Ref gr = game_ref(geo, (size_t)gi, true);
@@ -247,6 +249,8 @@ __global__ __launch_bounds__(CHAIN ? 64 : 256, CHAIN ? 5 : 1) void k_duo(KArgs a
         rpf.ok = 0; rpf.seed16 = 0; rpf.word = 0;
         uint32_t sent_start = 0;
         uint32_t wa = 0;
+        uint32_t undo_pose = 0, undo_group = 0, undo_draws = 0, undo_cleared = 0;
+        bool undo_ran = false;
         if (active) {
             if (ROLL) {
                 r = (int)(g.draw0 & 3u); t = (int)(g.draw1 % 10u); acting = (int)(a.first_step % 2ull);
@@ -258,22 +262,35 @@ __global__ __launch_bounds__(CHAIN ? 64 : 256, CHAIN ? 5 : 1) void k_duo(KArgs a
             sent_start = q.lines_sent;
             // stage A
             if (!g.round_over && !q.dead && acting == side) play_rt(cx, q, r, t);
+            // Player 1's loop-1 pass is speculative (the reference skips it when player 0 died in loop 1, PythonHandle.cpp:153-156,
+            // which this lane learns from the shuffle below).  What the pass changes when it clears no row and the new piece
+            // fits — nearly always — is the piece (kind, rotation, position, next), the draw counter, now and then the piece
+            // group, and 200 ms of combo time: an undo record of three registers.  (A full copy of the board in registers cost
+            // ~80 of them in every lane of every step; loading the state again and replaying the keys on EVERY rollback made the
+            // slowest wave of most launches ~2 us longer.)
+            undo_pose = (uint32_t)q.kind | ((uint32_t)q.rot << 3) | ((uint32_t)(q.x + 4) << 5) | ((uint32_t)q.y << 9) | ((uint32_t)q.next << 14);
+            undo_group = q.pgroup; undo_draws = q.piece_draws;
+            undo_cleared = q.lines_cleared; undo_ran = !g.round_over && !q.dead;
             wa = split_settle(cx, g);
         }
         const uint32_t opp_a = __shfl_xor(wa, 32);
         uint32_t wb0 = 0, wb1 = 0;
         if (active) {
             if (side == 1 && (opp_a & XW_DIED)) {
-                // Player 0 died in loop 1, so player 1 did not run it (PythonHandle.cpp:153-156): back to the board as it was after
-                // the key interpreter.  No copy of it is kept in registers (it cost ~40 of them in every lane of every step for a
-                // case that comes up once per episode at most): the launch has not stored anything yet, so the state before this
-                // step is still in memory — load it again and replay the keys.
-                const uint32_t keep = g.status;
-                load_player(br.s, br.o, br.ws, q, false, true, MEM);
-                prefetch_next(cx, q, g.seed16, g.status);
-                if (!g.round_over && !q.dead && acting == side) play_rt(cx, q, r, t);
-                sent_start = q.lines_sent;
-                g.status |= keep;
+                if (undo_ran && q.lines_cleared == undo_cleared && !q.dead) {
+                    // settle() with no row cleared and a spawn that fitted (gamePlay.cpp:54-59,71-88,160-171; Combo.cpp:50-52): undone in place
+                    q.kind = (int)(undo_pose & 7u); q.rot = (int)((undo_pose >> 3) & 3u); q.x = (int)((undo_pose >> 5) & 15u) - 4;
+                    q.y = (int)((undo_pose >> 9) & 31u); q.next = (int)((undo_pose >> 14) & 7u);
+                    q.pgroup = undo_group; q.piece_draws = undo_draws; q.pf_ok = 0;
+                    q.combo_time += 200;
+                } else if (undo_ran) {
+                    // rows were cleared or the new piece did not fit (rare together with a rollback): nothing has been stored by
+                    // this launch yet, so the state before this step is still in memory — load it again and replay the keys
+                    load_player(br.s, br.o, br.ws, q, false, true, MEM);
+                    prefetch_next(cx, q, g.seed16, g.status);
+                    if (!g.round_over && !q.dead && acting == side) play_rt(cx, q, r, t);
+                    sent_start = q.lines_sent;
+                }
                 wa = 0;
             }
             if (side == 0) {                                           // stage B0
@@ -835,19 +852,49 @@ static const void* chain_kernel(tetris_batch* b, long long* waves) {
     *waves = ((long long)b->N + 31) / 32;
     return (const void*)k_duo<M_ROLLOUT, true>;
 }
+// `waves` workgroups of the chained kernel resident at once?  Asked of the device itself: one census launch (chain_census).
+static bool chain_census_ok(tetris_batch* b, long long waves) {
+    uint32_t* d = nullptr;
+    if (hipMalloc((void**)&d, 2 * CHAIN_STRIDE * sizeof(uint32_t)) != hipSuccess) return false;
+    bool ok = false;
+    uint32_t h[2] = {0, 1};
+    KArgs a;
+    memset(&a, 0, sizeof a);
+    a.steps = -1; a.chain = d; a.epoch = (uint32_t)waves; a.chain_spin_limit = 4000;       // a few ms at most, and only where the answer is no
+    if (hipMemsetAsync(d, 0, 2 * CHAIN_STRIDE * sizeof(uint32_t), b->own_stream) == hipSuccess) {
+        if (b->P == 1) hipLaunchKernelGGL((k_chain<1>), dim3((unsigned)waves), dim3(64), 0, b->own_stream, a);
+        else hipLaunchKernelGGL((k_duo<M_ROLLOUT, true>), dim3((unsigned)waves), dim3(64), 0, b->own_stream, a);
+        if (hipGetLastError() == hipSuccess && hipMemcpyAsync(&h[0], d, 4, hipMemcpyDeviceToHost, b->own_stream) == hipSuccess &&
+            hipMemcpyAsync(&h[1], d + CHAIN_STRIDE, 4, hipMemcpyDeviceToHost, b->own_stream) == hipSuccess &&
+            hipStreamSynchronize(b->own_stream) == hipSuccess)
+            ok = h[0] == (uint32_t)waves && h[1] == 0;
+    }
+    (void)hipFree(d);
+    return ok;
+}
+
 static bool chain_fits(tetris_batch* b) {
     long long waves = 0;
     const void* fn = chain_kernel(b, &waves);
+    // TETRIS_CHAIN_DEPTH=1..3 (measurement aid): at most that many launches in flight.  1 = the chained kernel on ONE stream: its
+    // dispatches are then serialised by the stream — the reference point for per-dispatch PMC counters (profiles/pmc_summary.py).
+    static const int cap = [] { const char* e = getenv("TETRIS_CHAIN_DEPTH"); const int v = e ? atoi(e) : CHAIN_STREAMS; return v < 1 ? 1 : (v > CHAIN_STREAMS ? CHAIN_STREAMS : v); }();
     if (b->chain_capacity < 0) {
         int per_cu = 0, cus = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64, 0) != hipSuccess) per_cu = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b->device) != hipSuccess) cus = 0;
+        // The API's answer less one workgroup per CU is taken on trust (the API can be one too high: MI355X_MICROARCH.md, correctness
+        // boundaries).  A batch that would chain only WITH that last workgroup per CU — 64k two-player boards: two launches of
+        // 2 048 waves are exactly the 16 x 256 slots a 116-register kernel has — asks the device: a census launch of that many
+        // waves of the very kernel, once per batch.
         b->chain_capacity = per_cu > 1 ? (long long)(per_cu - 1) * cus : 0;
+        const long long full = (long long)per_cu * cus;
+        int want = 0;
+        for (int d = cap; d >= 2 && !want; d--)
+            if (d * waves <= full) want = d;
+        if (want && want * waves > b->chain_capacity && b->stream == b->own_stream && chain_census_ok(b, want * waves)) b->chain_capacity = want * waves;
     }
     b->chain_depth = 0;
-    // TETRIS_CHAIN_DEPTH=1..3 (measurement aid): at most that many launches in flight.  1 = the chained kernel on ONE stream: its
-    // dispatches are then serialised by the stream — the reference point for per-dispatch PMC counters (profiles/pmc_summary.py).
-    static const int cap = [] { const char* e = getenv("TETRIS_CHAIN_DEPTH"); const int v = e ? atoi(e) : CHAIN_STREAMS; return v < 1 ? 1 : (v > CHAIN_STREAMS ? CHAIN_STREAMS : v); }();
     for (int d = cap; d >= 1 && !b->chain_depth; d--)
         if (d * waves <= b->chain_capacity) b->chain_depth = d;
     return b->chain_depth >= (cap == 1 ? 1 : 2);

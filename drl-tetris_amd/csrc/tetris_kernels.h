@@ -140,6 +140,24 @@ TE_HD bool chain_wait(const KArgs& a, uint32_t wave, bool marker) {
     return false;
 }
 
+// Residency census of a chained kernel (a launch with a.steps < 0, the kernel's ordinary resource footprint): every wave counts
+// itself in and then waits until a.epoch waves have done so.  They can only all see the full count if that many waves of THIS
+// kernel are resident on the device at the same time — which is what chaining `depth` launches of it presumes (tetris_hip.hip:
+// chain_fits; MI355X_MICROARCH.md: the occupancy API can be off, verify with a census).  a.chain: [0] count, [CHAIN_STRIDE] != 0 = a
+// wave gave up.
+TE_HD void chain_census(const KArgs& a, bool marker) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (marker) (void)__hip_atomic_fetch_add(a.chain, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (uint32_t spin = 0; spin < a.chain_spin_limit; spin++) {
+        if (ld_agent(a.chain) >= a.epoch) return;
+        __builtin_amdgcn_s_sleep(8);
+    }
+    if (marker) st_agent(a.chain + CHAIN_STRIDE, 1u);
+#else
+    (void)a; (void)marker;
+#endif
+}
+
 TE_HD Ctx make_ctx(const KArgs& a, const uint32_t* shapes, bool tint = false, bool queue = true) {
     Ctx cx;
     cx.shapes = shapes;

@@ -3,7 +3,7 @@
 # split-mode stage times (two-kernel vs three-kernel form), drop-in Python API throughput, two-player bench line.
 set -x
 set -e -o pipefail
-O=gpurun_out/r03b
+O=gpurun_out/${OUT:-r03b}
 mkdir -p $O
 R=$GRAFT_REPO_ROOT
 timeout -k 10 1000 python -m pytest tests -m gpu -q -x > $O/pytest_gpu.log 2>&1 || { tail -40 $O/pytest_gpu.log; exit 1; }
