@@ -268,7 +268,7 @@ __global__ __launch_bounds__(CHAIN ? 64 : 256) void k_duo(KArgs a) {
             // group, and 200 ms of combo time: an undo record of three registers.  (A full copy of the board in registers cost
             // ~80 of them in every lane of every step; loading the state again and replaying the keys on EVERY rollback made the
             // slowest wave of most launches ~2 us longer.)
-            undo_pose = (uint32_t)q.kind | ((uint32_t)q.rot << 3) | ((uint32_t)(q.x + 4) << 5) | ((uint32_t)q.y << 9) | ((uint32_t)q.next << 14);
+            undo_pose = pose_pack(q);
             undo_group = q.pgroup; undo_draws = q.piece_draws;
             undo_cleared = q.lines_cleared; undo_ran = !g.round_over && !q.dead;
             wa = split_settle(cx, g);
@@ -278,11 +278,7 @@ __global__ __launch_bounds__(CHAIN ? 64 : 256) void k_duo(KArgs a) {
         if (active) {
             if (side == 1 && (opp_a & XW_DIED)) {
                 if (undo_ran && q.lines_cleared == undo_cleared && !q.dead) {
-                    // settle() with no row cleared and a spawn that fitted (gamePlay.cpp:54-59,71-88,160-171; Combo.cpp:50-52): undone in place
-                    q.kind = (int)(undo_pose & 7u); q.rot = (int)((undo_pose >> 3) & 3u); q.x = (int)((undo_pose >> 5) & 15u) - 4;
-                    q.y = (int)((undo_pose >> 9) & 31u); q.next = (int)((undo_pose >> 14) & 7u);
-                    q.pgroup = undo_group; q.piece_draws = undo_draws; q.pf_ok = 0;
-                    q.combo_time += 200;
+                    undo_simple_settle(q, undo_pose, undo_group, undo_draws);
                 } else if (undo_ran) {
                     // rows were cleared or the new piece did not fit (rare together with a rollback): nothing has been stored by
                     // this launch yet, so the state before this step is still in memory — load it again and replay the keys
@@ -1156,7 +1152,7 @@ static int create_impl(tetris_batch** out, int n_games, int n_players, int heigh
         d_seeds = (const int16_t*)b->s_in0.d;
     }
     b->split = split; b->side = side;
-    if (split && side == 1) CREATE_TRY(hipMalloc((void**)&b->d_shadow, state_bytes));
+    if (split && side == 1) CREATE_TRY(hipMalloc((void**)&b->d_shadow, (size_t)(UNDO_WORDS + b->nw) * (size_t)b->stride * 4));
     KArgs a = base_args(b, n_games, nullptr);
     a.seeds = d_seeds;
     a.steps = side;

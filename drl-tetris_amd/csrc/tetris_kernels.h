@@ -45,7 +45,7 @@ struct KArgs {
     uint32_t* chain;          // chained launches: one epoch word per wave (NULL = launches are ordered by the stream)
     uint32_t epoch;           // chained launches: this launch's number; its waves wait for epoch - 1 and publish epoch
     uint32_t chain_spin_limit; // chained launches: polls of the epoch word before a wave gives up (tetris_set_chain_spin_limit)
-    uint32_t* shadow;         // split mode, side 1: the player words as they were before the speculative loop-1 pass (rollback copy)
+    uint32_t* shadow;         // split mode, side 1: undo record of the speculative loop-1 pass, UNDO_WORDS + nw rows of n_stride words
     int split_side;           // split mode: the player index this batch holds
     const uint32_t* xw[4];    // split mode: exchange words [n] each: my A, the opponent's A, player 0's B, player 1's B (separate buffers:
                               // the words a kernel wrote and the rows an all-gather delivered are read where they lie, no copies)
@@ -321,9 +321,27 @@ TE_HD void game_run(const KArgs& a, int i, const uint32_t* shapes, Game<P>& g, L
 //   the state: C needs only the peer's last exchange word and A of the next step only what C leaves behind, both local once the
 //   gather has landed — a step of a device-driven loop is then TWO kernels (B, C+A) and two state round trips instead of three.
 // Player 1's loop-1 pass (stage A) is speculative: the reference skips it when player 0 died in loop 1 (PythonHandle.cpp:153-156),
-// which side 1 only learns from the exchange.  Side 1 therefore keeps the board as it was BEFORE the pass (post-make, pre-settle)
-// in the shadow array and continues from the main state; only a game whose player 0 did die reloads the shadow (rare: a lane's
-// second load, not a second state array on the critical path — stage B's loads do not wait for the exchange word).
+// which side 1 only learns from the exchange.  Side 1 continues from the main state and keeps an UNDO RECORD in the shadow array:
+// what the pass changes when it clears no row and the new piece fits — nearly always — is the piece (kind, rotation, position,
+// next), the draw counter, now and then the piece group, and 200 ms of combo time: four words per board instead of a second
+// copy of the state.  Where rows were cleared or the spawn failed (rare), the board as it was after the key interpreter is
+// rebuilt from memory (stage A has not stored anything yet) and kept whole behind the record.  Stage B reads the record only
+// for games whose player 0 did die.
+constexpr int UNDO_WORDS = 4;        // shadow rows: 0 pose, 1 piece group, 2 piece draws, 3 flags; the full copy follows from row UNDO_WORDS
+constexpr uint32_t UNDO_RAN = 1u, UNDO_SIMPLE = 2u;
+TE_HD Ref undo_ref(const KArgs& a, int i) { Ref r = {a.shadow, (uint32_t)i * 4u, (size_t)a.n_stride}; return r; }
+TE_HD Ref undo_copy_ref(const KArgs& a, int i) { Ref r = {a.shadow + (size_t)UNDO_WORDS * a.n_stride, (uint32_t)i * 4u, (size_t)a.n_stride}; return r; }
+TE_HD uint32_t pose_pack(const Player& q) {
+    return (uint32_t)q.kind | ((uint32_t)q.rot << 3) | ((uint32_t)(q.x + 4) << 5) | ((uint32_t)q.y << 9) | ((uint32_t)q.next << 14);
+}
+// settle() with no row cleared and a spawn that fitted (gamePlay.cpp:54-59,71-88,160-171; Combo.cpp:50-52), undone in place
+TE_HD void undo_simple_settle(Player& q, uint32_t pose, uint32_t group, uint32_t draws) {
+    q.kind = (int)(pose & 7u); q.rot = (int)((pose >> 3) & 3u); q.x = (int)((pose >> 5) & 15u) - 4;
+    q.y = (int)((pose >> 9) & 31u); q.next = (int)((pose >> 14) & 7u);
+    q.pgroup = group; q.piece_draws = draws; q.pf_ok = 0;
+    q.combo_time += 200;
+}
+
 template <bool TINT>
 TE_HD void split_stage_a(const KArgs& a, const Ctx& cx, int i, Game<1>& g, int side, unsigned long long step) {
     Player& q = g.pl[0];
@@ -336,14 +354,29 @@ TE_HD void split_stage_a(const KArgs& a, const Ctx& cx, int i, Game<1>& g, int s
         r = (int)(w[0] & 3u); t = (int)(w[1] % 10u); acting = (int)(step % 2ull);
     }
     prefetch_next(cx, q, g.seed16, g.status);
-    if (!g.round_over && !q.dead && acting == side) play_rt(cx, q, r, t);
-    if (side == 1) {                                      // rollback copy: the player words only (the game words are not speculative)
-        Geo geo = geo_of(a, a.shadow);
-        geo.P = 1;
-        const Ref br = board_ref(geo, 0, (size_t)i);
-        store_player(br.s, br.o, br.ws, q, TINT);
-    }
+    const bool plays = !g.round_over && !q.dead && acting == side;
+    if (plays) play_rt(cx, q, r, t);
+    const uint32_t pose = pose_pack(q), group = q.pgroup, draws = q.piece_draws, cleared = q.lines_cleared;
+    const bool ran = !g.round_over && !q.dead;
     a.xout[i] = split_settle(cx, g);
+    if (side == 1) {
+        const bool simple = ran && q.lines_cleared == cleared && !q.dead;
+        const Ref ur = undo_ref(a, i);
+        word_at(ur, 0) = pose; word_at(ur, 1) = group; word_at(ur, 2) = draws;
+        word_at(ur, 3) = (ran ? UNDO_RAN : 0u) | (simple ? UNDO_SIMPLE : 0u);
+        if (ran && !simple) {                             // rare: the whole board as the key interpreter left it
+            Geo geo = geo_of(a);
+            geo.P = 1;
+            const Ref br = board_ref(geo, 0, (size_t)i);
+            Player pre;
+            load_player(br.s, br.o, br.ws, pre, TINT);    // (this launch has not stored the game yet)
+            uint32_t scratch_status = 0;
+            prefetch_next(cx, pre, g.seed16, scratch_status);
+            if (plays) play_rt(cx, pre, r, t);
+            const Ref cr = undo_copy_ref(a, i);
+            store_player(cr.s, cr.o, cr.ws, pre, TINT);
+        }
+    }
     // rollout counter: side 1's loop-1 lines are counted at stage B, once it knows the pass is committed
     if (side == 0) g.add_sent += (q.lines_sent - sent_before) & 0xFFFFu;
 }
@@ -371,13 +404,15 @@ TE_HD void split_body(const KArgs& a, int i, const uint32_t* shapes) {
         } else {
             const uint32_t opp_b = a.xw[2][i];
             const bool committed = !(opp_a & XW_DIED);
-            if (!committed) {                             // player 0 died in loop 1: player 1 did not run (:153-156) — back to the copy
-                Geo geo = geo_of(a, a.shadow);
-                geo.P = 1;
-                const Ref br = board_ref(geo, 0, (size_t)i);
-                const uint32_t keep = g.status;
-                load_player(br.s, br.o, br.ws, q, TINT);
-                g.status = keep;
+            if (!committed) {                             // player 0 died in loop 1: player 1 did not run (:153-156) — undo its pass
+                const Ref ur = undo_ref(a, i);
+                const uint32_t flags = word_at(ur, 3);
+                if (flags & UNDO_SIMPLE) { TE_COUNT(PC_UNDO_SIMPLE); undo_simple_settle(q, word_at(ur, 0), word_at(ur, 1), word_at(ur, 2)); }
+                else if (flags & UNDO_RAN) {
+                    TE_COUNT(PC_UNDO_FULL);
+                    const Ref cr = undo_copy_ref(a, i);
+                    load_player(cr.s, cr.o, cr.ws, q, TINT);
+                }
             }
             const uint32_t sent_before = q.lines_sent;
             const int in1 = ((opp_a & XW_RAN) && !(opp_a & XW_DIED)) ? xw_sent(opp_a) : 0;

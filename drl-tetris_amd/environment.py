@@ -85,10 +85,15 @@ class tetris_environment_vector:
         self._shared_zero = self._zero_reward()
         self.done = np.zeros(n_envs, bool)
         self.rounds_played = np.zeros(n_envs, np.int64)
-        self.round_reward = [[self._zero_reward() for _ in self.player_idxs] for _ in range(n_envs)]
-        self.tot_reward = [[self._zero_reward() for _ in self.player_idxs] for _ in range(n_envs)]
-        self._last_reward = [[None for _ in self.player_idxs] for _ in range(n_envs)]
-        self._last_pending = None
+        # running reward sums per (env, player) as numbers; the reward OBJECTS of get_info are made from them when asked for.  A
+        # maingoal_reward sum only ever accumulates component 0 of what is added (reward.py:64-71), so one number per entry is
+        # the whole state, plus whether a two-component reward (extra_rewards) has been added (the sum then has two components)
+        self._round_sum = np.zeros((n_envs, self.n_players), np.float64)
+        self._tot_sum = np.zeros((n_envs, self.n_players), np.float64)
+        self._round_two = np.zeros((n_envs, self.n_players), bool)
+        self._tot_two = np.zeros((n_envs, self.n_players), bool)
+        self._shared_win, self._shared_loss = maingoal_reward([1]), maingoal_reward([-1])
+        self._last_reward = np.full((n_envs, self.n_players), None, dtype=object)      # (an array: one assignment per step, not a loop)
         if init_envs is None or (type(init_envs) is list and all(e is None for e in init_envs)):
             self.reset()                       # "upon agreement with backend, we always reset once" (tetris_environment.py:40-41)
         else:
@@ -121,15 +126,22 @@ class tetris_environment_vector:
         states._batch = batch
         return states
 
+    def _sum_objects(self, sums, two, i):
+        return [maingoal_reward([sums[i, p], 0.0] if two[i, p] else [int(sums[i, p])]) for p in self.player_idxs]
+
+    @property
+    def round_reward(self):
+        """[n_envs][n_players] reward objects: the sum of each player's rewards since the env's last reset"""
+        return [self._sum_objects(self._round_sum, self._round_two, i) for i in range(self.n_envs)]
+
+    @property
+    def tot_reward(self):
+        return [self._sum_objects(self._tot_sum, self._tot_two, i) for i in range(self.n_envs)]
+
     @property
     def last_reward(self):
-        """reward object of each env's last perform_action, per player (written back lazily: one Python loop per LOOK, not per step)"""
-        pending, self._last_pending = self._last_pending, None
-        if pending is not None:
-            idx, who, rewards = pending
-            for j in range(len(idx)):
-                self._last_reward[idx[j]][who[j]] = rewards[j]
-        return self._last_reward
+        """reward object of each env's last perform_action, per player: [n_envs][n_players] (tetris_environment.py:111)"""
+        return self._last_reward.tolist()
 
     def _reward(self, done, dead, player):
         """tetris_environment.reward_fcn (tetris_environment.py:135-149)"""
@@ -173,10 +185,10 @@ class tetris_environment_vector:
             return []
         self.backend.reset(idx, seeds=self._seed_source())
         self.done[idx] = False
-        for i in idx:
-            self.rounds_played[i] += 1
-            self.round_reward[i] = [self._zero_reward() for _ in self.player_idxs]
-        return [None for _ in idx]
+        self.rounds_played[idx] += 1
+        self._round_sum[idx] = 0.0
+        self._round_two[idx] = False
+        return [None] * len(idx)
 
     def perform_action(self, actions, env=None, player=None):
         idx = self._idx(env)
@@ -194,6 +206,7 @@ class tetris_environment_vector:
         self.done[idx] = done_b
         zero = self._shared_zero
         rewards = [zero] * n
+        self._last_reward[idx, who] = zero
         if self.settings["extra_rewards"]:
             # tetris_environment.py:144-149: two components, [w_base * win/lose signal, w_combo * my combo count], every step
             w_base, w_combo = self.settings["reward_ammount"]
@@ -201,19 +214,22 @@ class tetris_environment_vector:
             for j in range(n):
                 i, p = idx[j], int(who[j])
                 r = maingoal_reward([w_base * self._reward(bool(done_b[j]), dead[j], p), w_combo * int(combo[j])])
-                rewards[j] = r
-                self.round_reward[i][p] = self.round_reward[i][p] + r
-                self.tot_reward[i][p] = self.tot_reward[i][p] + r
-        for j in (() if self.settings["extra_rewards"] else np.nonzero(done_b)[0]):
-            i, p = idx[j], int(who[j])
-            base = self._reward(True, dead[j], p)
-            if base != 0:
-                r = maingoal_reward([base])
-                rewards[j] = r
-                self.round_reward[i][p] = self.round_reward[i][p] + r
-                self.tot_reward[i][p] = self.tot_reward[i][p] + r
-        self.last_reward                              # (apply what an earlier call left pending, then leave this call's)
-        self._last_pending = (idx, who, rewards)
+                rewards[j] = self._last_reward[i, p] = r
+                self._round_sum[i, p] += r.extrinsic[0]
+                self._tot_sum[i, p] += r.extrinsic[0]
+            self._round_two[idx, who] = True
+            self._tot_two[idx, who] = True
+        else:
+            dj = np.nonzero(done_b)[0]
+            if len(dj):
+                # reward_fcn for the envs whose round ended, all at once: you dead - me dead, -1 when both are
+                me = dead[dj, who[dj]].astype(np.int64)
+                you = dead[dj, 1 - who[dj]].astype(np.int64) if self.n_players > 1 else np.zeros(len(dj), np.int64)
+                base = np.where((me == 1) & (you == 1), -1, you - me)
+                np.add.at(self._round_sum, (idx[dj], who[dj]), base)
+                np.add.at(self._tot_sum, (idx[dj], who[dj]), base)
+                for j, v in zip(dj[base != 0].tolist(), base[base != 0].tolist()):      # (the +-1 reward objects are shared too)
+                    rewards[j] = self._last_reward[idx[j], who[j]] = self._shared_win if v > 0 else self._shared_loss
         return rewards, done_b.tolist()
 
     def get_state(self, env=None):
@@ -308,7 +324,8 @@ class tetris_environment_vector:
         rec, _, _ = self.backend.observe(idx)
         last = self.last_reward
         return [{"is_dead": [rec[j, p]["dead"] for p in self.player_idxs], "reward": last[i],
-                 "tot_reward": self.tot_reward[i], "round_reward": self.round_reward[i],
+                 "tot_reward": self._sum_objects(self._tot_sum, self._tot_two, i),
+                 "round_reward": self._sum_objects(self._round_sum, self._round_two, i),
                  "rounds_played": int(self.rounds_played[i])} for j, i in enumerate(idx)]
 
     def get_fields(self, env=None):
@@ -330,7 +347,6 @@ class tetris_environment_vector:
         """Everything but the device handle: settings, reward bookkeeping and the games as snapshot words.  Unlike the
         reference's pickle (PythonHandle.h:180-182 drops the generators) the RNG positions survive.  A `seed_source` that
         cannot be pickled (a lambda) is replaced by the default wall-clock source on load."""
-        self.last_reward                              # (nothing pending in the pickle)
         d = {k: v for k, v in self.__dict__.items() if k not in ("backend", "state_processor", "_seed_source")}
         d["settings"] = dict(self.settings)
         try:

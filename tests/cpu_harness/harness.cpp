@@ -183,7 +183,7 @@ static int create_impl(tetris_batch** out, int n_games, int n_players, int heigh
     b->gstate.assign(gstate_words((size_t)n_games), 0);
     b->tab = tables_for(piece_map);
     b->split = split; b->side = side;
-    if (split && side == 1) b->shadow.assign(state_words((size_t)n_games, n_players, b->nw), 0);
+    if (split && side == 1) b->shadow.assign((size_t)(UNDO_WORDS + b->nw) * (size_t)n_games, 0);
     KArgs a = base_args(b, n_games, nullptr);
     a.seeds = seeds; a.steps = side;
     if (split) run<M_SPLIT_INIT>(b, a); else run<M_INIT>(b, a);

@@ -61,7 +61,10 @@ def _worker(rank, world, port, out_dir, scenario, pieces):
         if s % CHECK_EVERY == CHECK_EVERY - 1:
             mid.append(so.batch.observe()[0])          # state right after this step's resets
     rec, ro, lw = so.batch.observe()
-    np.savez(os.path.join(out_dir, f"side{rank}.npz"), rec=rec, ro=ro, lw=lw, dones=np.stack(dones), mid=np.stack(mid))
+    from tests import engines
+    counts = engines.harness_path_counts()
+    np.savez(os.path.join(out_dir, f"side{rank}.npz"), rec=rec, ro=ro, lw=lw, dones=np.stack(dones), mid=np.stack(mid),
+             undo=np.array([counts["undo_simple"], counts["undo_full"]]))
     so.close()
     dist.destroy_process_group()
 
@@ -95,6 +98,9 @@ def test_split_opponents_equal_colocated_game(tmp_path, scenario, pieces):
         assert sent_total > 300 and max_queue >= 2 and max_combo >= 2, (sent_total, max_queue, max_combo)
     else:
         assert sent_total > 20
+    undo = np.load(os.path.join(str(tmp_path), "side1.npz"))["undo"]
+    print("undo paths on side 1 (in place, from the full copy):", undo.tolist())
+    assert undo[0] > 0                                     # player 1's speculative pass was taken back at all
     for side in (0, 1):
         got = np.load(os.path.join(str(tmp_path), f"side{side}.npz"))
         assert np.array_equal(got["dones"], np.stack(want_dones)), f"done flags differ on side {side}"
