@@ -99,7 +99,7 @@ __device__ __forceinline__ void te_stamp_place(uint32_t epoch) {
 #if defined(TE_PATH_COUNTERS) && !defined(__HIPCC__)
 enum PathCounter { PC_KICK = 0, PC_KICK_2ND, PC_KICK_3RD, PC_KICK_FAILED, PC_KICK_DOWN, PC_DROP_EXACT, PC_RT_OFF_SPAWN,
                    PC_GARBAGE_ROW, PC_GARBAGE_LIFT2, PC_DEATH_GARBAGE, PC_DEATH_SPAWN, PC_TIMER_LOCK, PC_KEY_KICK, PC_KEY_KICK_FAILED,
-                   PC_UNDO_SIMPLE, PC_UNDO_FULL, PC_UNDO_IDLE, PC_NCOUNTERS };
+                   PC_UNDO_SIMPLE, PC_UNDO_FULL, PC_UNDO_MISPREDICT, PC_NCOUNTERS };
 extern unsigned long long te_path_count[PC_NCOUNTERS];
 #define TE_COUNT(i) (te_path_count[i]++)
 #else

@@ -358,25 +358,25 @@ TE_HD void split_stage_a(const KArgs& a, const Ctx& cx, int i, Game<1>& g, int s
     if (plays) play_rt(cx, q, r, t);
     const uint32_t pose = pose_pack(q), group = q.pgroup, draws = q.piece_draws, cleared = q.lines_cleared;
     const bool ran = !g.round_over && !q.dead;
-    a.xout[i] = split_settle(cx, g);
     if (side == 1) {
-        const bool simple = ran && q.lines_cleared == cleared && !q.dead;
+        // Will the pass be the simple kind?  Known BEFORE it runs: no row in the scanned range is full (gameField.cpp:120-145)
+        // and, the board then staying as it is, the next piece fits where it appears (gamePlay.cpp:71-88).  A board for which
+        // that does not hold goes to the shadow whole, now, while it still is what the key interpreter left — a store by the few
+        // lanes concerned instead of a copy kept by all.
+        uint32_t full = (~0u << q.y) & ~cx.floor_bits;
+        for (int c = 0; c < NCOL; c++) full &= q.col[c];
+        const bool simple = ran && !full && fits_spawn_col(cx, q, shape_of(cx, q.next, spawn_rot(q.next)), 0);
         const Ref ur = undo_ref(a, i);
         word_at(ur, 0) = pose; word_at(ur, 1) = group; word_at(ur, 2) = draws;
         word_at(ur, 3) = (ran ? UNDO_RAN : 0u) | (simple ? UNDO_SIMPLE : 0u);
-        if (ran && !simple) {                             // rare: the whole board as the key interpreter left it
-            Geo geo = geo_of(a);
-            geo.P = 1;
-            const Ref br = board_ref(geo, 0, (size_t)i);
-            Player pre;
-            load_player(br.s, br.o, br.ws, pre, TINT);    // (this launch has not stored the game yet)
-            uint32_t scratch_status = 0;
-            prefetch_next(cx, pre, g.seed16, scratch_status);
-            if (plays) play_rt(cx, pre, r, t);
+        if (ran && !simple) {
             const Ref cr = undo_copy_ref(a, i);
-            store_player(cr.s, cr.o, cr.ws, pre, TINT);
+            store_player(cr.s, cr.o, cr.ws, q, TINT);
         }
-    }
+        a.xout[i] = split_settle(cx, g);
+        if (simple && (q.lines_cleared != cleared || q.dead)) TE_COUNT(PC_UNDO_MISPREDICT);      // (tests assert this never counts)
+    } else
+        a.xout[i] = split_settle(cx, g);
     // rollout counter: side 1's loop-1 lines are counted at stage B, once it knows the pass is committed
     if (side == 0) g.add_sent += (q.lines_sent - sent_before) & 0xFFFFu;
 }

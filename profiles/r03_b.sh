@@ -27,3 +27,7 @@ for r in d['rows']: print(r['n_envs'], r['variant'], '%.3g env-steps/s' % r['env
 for c in step_auto_1p step_auto_2p step_obs_1p step_obs_2p; do timeout -k 10 200 python profiles/kernel_prof.py $c > $O/kernel_$c.json 2>/dev/null; cut -c1-160 $O/kernel_$c.json; done
 timeout -k 10 300 python profiles/dropin_breakdown.py default 4096 > $O/dropin_breakdown.json 2>/dev/null; cat $O/dropin_breakdown.json
 TETRIS_NO_CHAIN=1 timeout -k 10 200 python bench.py --players 2 --cpu-seconds 0 > $O/bench_p2_s1_unchained.json 2>/dev/null; cut -c1-200 $O/bench_p2_s1_unchained.json
+for rep in 1 2; do for P in 2 1; do
+  timeout -k 10 120 python profiles/ab_old_lib.py profiles/_ab/libtetris_r02.so $P 2>/dev/null >> $O/ab_r02.txt
+  timeout -k 10 120 python profiles/ab_old_lib.py default $P 2>/dev/null >> $O/ab_r02.txt
+done; done; cat $O/ab_r02.txt

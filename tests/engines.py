@@ -48,7 +48,7 @@ def assert_same_state(eng, ref, idx=None, where=""):
 
 PATH_COUNTERS = ["kick", "kick_2nd", "kick_3rd", "kick_failed", "kick_down", "drop_exact", "rt_off_spawn",
                  "garbage_row", "garbage_lift2", "death_garbage", "death_spawn", "timer_lock", "key_kick", "key_kick_failed",
-                 "undo_simple", "undo_full", "undo_idle"]
+                 "undo_simple", "undo_full", "undo_mispredict"]
 
 
 def harness_path_counts():

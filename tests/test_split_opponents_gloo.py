@@ -64,7 +64,7 @@ def _worker(rank, world, port, out_dir, scenario, pieces):
     from tests import engines
     counts = engines.harness_path_counts()
     np.savez(os.path.join(out_dir, f"side{rank}.npz"), rec=rec, ro=ro, lw=lw, dones=np.stack(dones), mid=np.stack(mid),
-             undo=np.array([counts["undo_simple"], counts["undo_full"]]))
+             undo=np.array([counts["undo_simple"], counts["undo_full"], counts["undo_mispredict"]]))
     so.close()
     dist.destroy_process_group()
 
@@ -100,7 +100,7 @@ def test_split_opponents_equal_colocated_game(tmp_path, scenario, pieces):
         assert sent_total > 20
     undo = np.load(os.path.join(str(tmp_path), "side1.npz"))["undo"]
     print("undo paths on side 1 (in place, from the full copy):", undo.tolist())
-    assert undo[0] > 0                                     # player 1's speculative pass was taken back at all
+    assert undo[0] > 0 and undo[2] == 0                    # player 1's speculative pass was taken back at all; "simple" was never mispredicted
     for side in (0, 1):
         got = np.load(os.path.join(str(tmp_path), f"side{side}.npz"))
         assert np.array_equal(got["dones"], np.stack(want_dones)), f"done flags differ on side {side}"
