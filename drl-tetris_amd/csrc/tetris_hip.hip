@@ -251,6 +251,7 @@ __global__ __launch_bounds__(CHAIN ? 64 : 256) void k_duo(KArgs a) {
         uint32_t wa = 0;
         uint32_t undo_pose = 0, undo_group = 0, undo_draws = 0, undo_cleared = 0;
         bool undo_ran = false;
+        Player pre;                                                    // un-chained kernels only: player 1's board before its speculative pass
         if (active) {
             if (ROLL) {
                 r = (int)(g.draw0 & 3u); t = (int)(g.draw1 % 10u); acting = (int)(a.first_step % 2ull);
@@ -267,7 +268,12 @@ __global__ __launch_bounds__(CHAIN ? 64 : 256) void k_duo(KArgs a) {
             // fits — nearly always — is the piece (kind, rotation, position, next), the draw counter, now and then the piece
             // group, and 200 ms of combo time: an undo record of three registers.  (A full copy of the board in registers cost
             // ~80 of them in every lane of every step; loading the state again and replaying the keys on EVERY rollback made the
-            // slowest wave of most launches ~2 us longer.)
+            // slowest wave of most launches ~2 us longer.)  The chained kernel — which has to stay within 128 registers for two
+            // launches of 64k games to fit on the device — falls back to that reload where the record does not do; a wave that
+            // takes it (1-2 % of them per launch) delays only its own chain.  The un-chained kernels keep the copy in registers
+            // instead (they have room): there a launch ends with its SLOWEST wave, and one reload per launch cost every launch
+            // 1.4 us (10.0 against 8.6 us, same box: profiles/r03/ab_r02.txt).
+            if (!CHAIN && side == 1) pre = q;
             undo_pose = pose_pack(q);
             undo_group = q.pgroup; undo_draws = q.piece_draws;
             undo_cleared = q.lines_cleared; undo_ran = !g.round_over && !q.dead;
@@ -277,7 +283,9 @@ __global__ __launch_bounds__(CHAIN ? 64 : 256) void k_duo(KArgs a) {
         uint32_t wb0 = 0, wb1 = 0;
         if (active) {
             if (side == 1 && (opp_a & XW_DIED)) {
-                if (undo_ran && q.lines_cleared == undo_cleared && !q.dead) {
+                if (!CHAIN) {
+                    q = pre;
+                } else if (undo_ran && q.lines_cleared == undo_cleared && !q.dead) {
                     undo_simple_settle(q, undo_pose, undo_group, undo_draws);
                 } else if (undo_ran) {
                     // rows were cleared or the new piece did not fit (rare together with a rollback): nothing has been stored by

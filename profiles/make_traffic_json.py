@@ -41,7 +41,10 @@ def fabric_bytes(k):
 
 d = json.load(open(summary))
 name, k = pick(d, want)
-cname, ck = pick(json.load(open(calib)), want.split("<")[0])
+cal = json.load(open(calib))
+# the zero-step calibration launches: the same kernel for one player; for two players the un-chained one-lane kernel k_game<2, 6>
+# (a zero-step launch is not a k_duo launch) — the same coalesced dword-per-lane rows, the same words
+cname, ck = pick(cal, want.split("<")[0] if any(want.split("<")[0] in n for n in cal) else f"k_game<{P}, 6")
 floor = STORED_WORDS[P] * 4 * GAMES
 write, read_raw = fabric_bytes(k)
 cwrite, cread_raw = fabric_bytes(ck)

@@ -1,0 +1,39 @@
+#!/bin/bash
+# Round 3, final collection, part A: parity suite, smoke, the bench lines, rocprofv3 kernel traces of the SAME bench commands
+# (chained one- and two-player, un-chained from graphs), the chained periods from the traces' own timestamps, split mode, secondary
+# kernels, the drop-in Python API.  Everything lands in gpurun_out/final3a; profiles/r03_collect.sh copies the judged files.
+set -x
+set -e -o pipefail
+O=gpurun_out/final3a
+mkdir -p $O
+R=$GRAFT_REPO_ROOT
+timeout -k 10 1000 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1 || { tail -40 $O/pytest_gpu.log; exit 1; }
+tail -1 $O/pytest_gpu.log
+timeout -k 10 200 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
+timeout -k 10 300 python bench.py > $O/bench_p1_s1.json 2> $O/bench_p1_s1.err
+timeout -k 10 300 python bench.py --steps 20 --warmup 5 > $O/bench_p1_s1_driver_flags.json 2>/dev/null
+timeout -k 10 200 python bench.py --players 2 --cpu-seconds 0 > $O/bench_p2_s1.json 2>/dev/null
+TETRIS_NO_CHAIN=1 timeout -k 10 200 python bench.py --cpu-seconds 0 > $O/bench_p1_s1_unchained.json 2>/dev/null
+TETRIS_NO_CHAIN=1 timeout -k 10 200 python bench.py --players 2 --cpu-seconds 0 > $O/bench_p2_s1_unchained.json 2>/dev/null
+timeout -k 10 200 python bench.py --steps 256 --warmup 8 --steps-per-launch 32 --cpu-seconds 0 > $O/bench_p1_s32.json 2>/dev/null
+prof() { (cd /tmp; export TMPDIR=/tmp; timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/$1 -- python3 "${@:2}" > $R/$O/$1.log 2>&1); }
+prof prof_p1 $R/bench.py --cpu-seconds 0
+prof prof_p2 $R/bench.py --cpu-seconds 0 --players 2
+python profiles/chain_period_from_trace.py $O/prof_p1 $O/chain_period_from_trace_p1.json > /dev/null
+python profiles/chain_period_from_trace.py $O/prof_p2 $O/chain_period_from_trace_p2.json > /dev/null
+grep -h period_us_of $O/chain_period_from_trace_p1.json $O/chain_period_from_trace_p2.json
+export TETRIS_NO_CHAIN=1 TETRIS_GRAPH=1
+prof prof_p1_unchained $R/bench.py --cpu-seconds 0
+prof prof_p2_unchained $R/bench.py --cpu-seconds 0 --players 2
+unset TETRIS_NO_CHAIN TETRIS_GRAPH
+timeout -k 10 200 python profiles/split_stages.py > $O/split_stages.json 2>/dev/null; cat $O/split_stages.json
+prof prof_split $R/profiles/split_stages.py 256
+for c in enum_planar observe step_auto_1p step_auto_2p step_obs_1p step_obs_2p; do
+  timeout -k 10 200 python profiles/kernel_prof.py $c > $O/kernel_$c.json 2>/dev/null
+  prof prof_$c $R/profiles/kernel_prof.py $c
+done
+timeout -k 10 300 python profiles/dropin_api.py > $O/dropin_api.json 2>/dev/null
+timeout -k 10 300 python profiles/dropin_breakdown.py default 4096 > $O/dropin_breakdown.json 2>/dev/null
+python profiles/order_check.py 1 > $O/order_check_p1.txt 2>&1
+python profiles/order_check.py 2 > $O/order_check_p2.txt 2>&1
+cut -c1-300 $O/bench_p1_s1.json
