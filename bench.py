@@ -314,16 +314,21 @@ def main():
         launch_us_events = ev_ms * 1e3 / args.steps if ev_ms > 0 else None     # (the CPU rehearsal library has no events)
         lib_path = os.path.abspath(os.environ.get("BENCH_LIB_PATH") or ge.LIB)
         roofline = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "kernel": "k_chain<1> (chained launches: three streams, each wave waits for its own predecessor's epoch word)" if chained
+                    "kernel": (("k_chain<1>" if P == 1 else "k_duo<M_ROLLOUT, true>") + " (chained launches: consecutive launches on "
+                               + ("three" if P == 1 else "two") + " streams, each wave waits for its own predecessor's epoch word)") if chained
                               else ("k_duo<M_ROLLOUT>" if (P == 2 and S == 1) else f"k_game<{P}, M_ROLLOUT>"),
                     "launch_us": launch_us, "launch_us_events": launch_us_events, "clock": "wall (same clock as `value`)"}
         if chained:
             roofline["launch_us_is"] = ("the launch PERIOD: consecutive launches overlap (a wave of launch E starts as soon as the same wave of "
-                                        "launch E-1 has published its state), so the durations in a kernel trace are longer than the period; "
-                                        "TETRIS_NO_CHAIN=1 puts every launch on one stream (k_game<1, M_ROLLOUT>): profiles/r02/")
+                                        "launch E-1 has published its state), so the durations in a kernel trace are longer than the period "
+                                        "(profiles/r03/final/chain_period_from_trace_p*.json derives the period from the trace's own timestamps); "
+                                        "TETRIS_NO_CHAIN=1 puts every launch on one stream")
         if S == 1:
             algo_bytes = ALGO_BYTES[P] * N                            # per launch, per GPU: SURVEY §8(d) bytes x games
             achieved = algo_bytes / (launch_us * 1e-6) / 1e9
+            if achieved > HBM_PEAK_GBS:
+                roofline["frac_note"] = ("above 1: SURVEY 8(d)'s algorithmic bytes (192 B in + 192 B out per player-board) are a budget, not what the kernel "
+                                         "moves (measured `traffic` is lower), and the 20 MB state of 64k two-player games lives in the 256 MB Infinity Cache")
             roofline.update({"achieved": achieved, "frac": achieved / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": algo_bytes,
                              "frac_kernel": (algo_bytes / (launch_us_events * 1e-6) / 1e9 / HBM_PEAK_GBS) if launch_us_events else None})
             if gpu_paced_us:

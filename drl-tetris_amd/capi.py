@@ -316,7 +316,7 @@ class TetrisBatch:
         planar: rotation-minor planes — valid / land_y / cleared [n][10][4], after [10][n][10][4]."""
         self._check(self.lib.tetris_enumerate_drops_dev_ex(self._h, idx, int(n), player, valid, land_y, cleared, after, 1 if planar else 0))
 
-    def get_actions(self, idx=None, player=None, max_lists=64, max_keys=48):
+    def get_actions(self, idx=None, player=None, max_lists=64, max_keys=48, with_masks=False):
         """The reference's ordered key lists per game (PythonHandle.get_actions; masks[p].action).
         `idx` may be an int (one game -> one list of lists) or None/array (-> list per game)."""
         single = isinstance(idx, (int, np.integer))
@@ -327,6 +327,11 @@ class TetrisBatch:
         count = np.zeros(n, np.int32)
         self._check(self.lib.tetris_get_actions(self._h, _p(a), n, _p(pl), _p(keys), _p(lens), _p(count), max_lists, max_keys))
         out = [[keys[i, k, : lens[i, k]].tolist() for k in range(count[i])] for i in range(n)]
+        if with_masks:
+            # PythonHandle.masks[p].mask after get_actions (PythonHandle.h:317-325): TestField::getMask(2) pushes one 1 per key list
+            # (TestField.cpp:113-133), i.e. a vector of ones as long as the list of actions — probed against the compiled reference
+            masks = [[1] * int(c) for c in count]
+            return (out[0], masks[0]) if single else (out, masks)
         return out[0] if single else out
 
     def rollout_random(self, launches, steps_per_launch=1, policy_seed=0xD71, first_step=0, ms=400):

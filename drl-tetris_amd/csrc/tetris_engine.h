@@ -157,6 +157,12 @@ TE_HD void add_word(uint32_t* p, uint32_t v) { (void)__hip_atomic_fetch_add(p, v
 #else
 TE_HD void add_word(uint32_t* p, uint32_t v) { *p += v; }
 #endif
+// a * b for a, b < 2^24 whose product fits 32 bits: a full-rate multiply on the GPU (a 32 x 32 one takes four passes)
+#if defined(__HIP_DEVICE_COMPILE__)
+TE_HD uint32_t mul24(uint32_t a, uint32_t b) { return __umul24(a, b); }
+#else
+TE_HD uint32_t mul24(uint32_t a, uint32_t b) { return a * b; }
+#endif
 TE_HD int imin(int a, int b) { return a < b ? a : b; }
 TE_HD int imax(int a, int b) { return a > b ? a : b; }
 TE_HD uint32_t f2u(float f) { union { float f; uint32_t u; } v; v.f = f; return v.u; }
@@ -546,8 +552,8 @@ TE_HD uint32_t table_byte(const Ctx& cx, uint32_t seed16, uint32_t draw, uint32_
         if (draw >= cx.n_draws) { status |= ST_STREAM_EXHAUSTED; draw = cx.n_draws - 1; }
     }
     uint32_t chunk = draw / (uint32_t)CHUNK;
-    uint32_t r = draw - chunk * (uint32_t)CHUNK;
-    return cx.table[((size_t)chunk * 65536u + seed16) * CHUNK + r];
+    uint32_t r = draw - mul24(chunk, (uint32_t)CHUNK);
+    return cx.table[mul24((chunk << 16) + seed16, (uint32_t)CHUNK) + r];       // < MAX_CHUNKS * 65536 * 624 < 2^32
 }
 
 // raw 8 table bytes of the aligned group of draws that holds `draw` (draw % 8 == 0 expected).  Loading and packing
@@ -558,8 +564,8 @@ TE_HD Raw8 table_group_raw(const Ctx& cx, uint32_t seed16, uint32_t draw, uint32
         if (draw + 8u > cx.n_draws) { status |= ST_STREAM_EXHAUSTED; draw = cx.n_draws - 8u; }
     }
     uint32_t chunk = draw / (uint32_t)CHUNK;
-    uint32_t r = draw - chunk * (uint32_t)CHUNK;                      // multiple of 8; 624 = 8 * 78: never straddles
-    const uint8_t* p = cx.table + ((size_t)chunk * 65536u + seed16) * CHUNK + r;
+    uint32_t r = draw - mul24(chunk, (uint32_t)CHUNK);                // multiple of 8; 624 = 8 * 78: never straddles
+    const uint8_t* p = cx.table + (mul24((chunk << 16) + seed16, (uint32_t)CHUNK) + r);       // (a 32-bit index: < 2^32)
     Raw8 v;
 #if defined(__HIP_DEVICE_COMPILE__)
     const uint2 w = *reinterpret_cast<const uint2*>(p);               // 8-byte aligned
@@ -1022,6 +1028,55 @@ TE_HD uint32_t band_win32(uint64_t band, int p) {
 #endif
 }
 
+// The ten columns seen from row y down, floor included: v[c] = (col[c] | floor) >> y.  Everything play_rt asks of the board at one
+// height — the band window of row y, the band window of row y + 1 (kicks), the free depth under the piece (hard drop) — is a
+// function of these ten words, so they are made once (20 instructions) instead of once per question.
+struct RowsFrom { uint32_t v[NCOL]; };
+TE_HD RowsFrom rows_from(const Ctx& cx, const Player& q, int y) {
+    RowsFrom r;
+    for (int c = 0; c < NCOL; c++) r.v[c] = (uint32_t)((int32_t)(q.col[c] | cx.floor_bits) >> y);
+    return r;
+}
+TE_HD uint64_t band_of_rows(const RowsFrom& r) {           // = band_window(cx, q, y)
+    uint32_t lo = 0xFFu, hi = 0xFFFF0000u;
+    for (int c = 0; c < 6; c++) lo |= (r.v[c] & 0xFu) << (4 * c + 8);
+    for (int c = 6; c < NCOL; c++) hi |= (r.v[c] & 0xFu) << (4 * (c - 6));
+    return ((uint64_t)hi << 32) | lo;
+}
+// band_window(cx, q, y + 1) from the window of row y: every column nibble moves down one bit and takes row y + 4 in at the top
+TE_HD uint64_t band_one_down(uint64_t band, const RowsFrom& r) {
+    uint32_t lo = (uint32_t)band, hi = (uint32_t)(band >> 32);
+    lo = ((lo >> 1) & 0x77777777u) | 0xFFu;              // (the mask also drops the bit that crosses in from the next nibble)
+    hi = ((hi >> 1) & 0x77777777u) | 0xFFFF0000u;
+    for (int c = 0; c < 6; c++) lo |= (r.v[c] & 0x10u) << (4 * c + 7);
+    hi |= (r.v[6] & 0x10u) >> 1;
+    for (int c = 7; c < NCOL; c++) hi |= (r.v[c] & 0x10u) << (4 * (c - 6) - 1);
+    return ((uint64_t)hi << 32) | lo;
+}
+// drop_distance_bytes with the depths taken from the rows (v = the columns from the piece's row down): same result
+TE_HD int drop_distance_rows(const Ctx& cx, const Player& q, const RowsFrom& r, uint32_t shape, uint32_t drop_word) {
+    uint32_t d[NCOL];
+    for (int c = 0; c < NCOL; c++) d[c] = (uint32_t)ctz32(r.v[c]);     // y <= H: never zero
+    const uint32_t w0 = (d[0] << 16) | (d[1] << 24);
+    const uint32_t w1 = d[2] | (d[3] << 8) | (d[4] << 16) | (d[5] << 24);
+    const uint32_t w2 = d[6] | (d[7] << 8) | (d[8] << 16) | (d[9] << 24);
+    const unsigned xs = (unsigned)(q.x + 2);           // 0..12 for a piece that fits
+    const bool hi2 = (xs & 8u) != 0, hi1 = (xs & 4u) != 0;
+    const uint32_t lo = hi2 ? (hi1 ? 0u : w2) : (hi1 ? w1 : w0);
+    const uint32_t hi = hi2 ? 0u : (hi1 ? w2 : w1);
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t under = __builtin_amdgcn_alignbyte(hi, lo, xs & 3u);
+#else
+    const uint32_t under = (uint32_t)((((uint64_t)hi << 32) | lo) >> (8 * (xs & 3u)));
+#endif
+    const uint32_t sum = under + drop_word;            // bytes <= 32 + 0x7F: no carries between bytes
+    const uint32_t b0 = sum & 0xFFu, b1 = (sum >> 8) & 0xFFu, b2 = (sum >> 16) & 0xFFu, b3 = sum >> 24;
+    const uint32_t m01 = b0 < b1 ? b0 : b1, m23 = b2 < b3 ? b2 : b3;
+    const uint32_t m = m01 < m23 ? m01 : m23;
+    if (m - 0x40u > 0x3Eu) { TE_COUNT(PC_DROP_EXACT); return drop_distance(cx, q, shape); }      // overhang (m < 0x40) or no piece at all (m >= 0x7F)
+    return (int)(m - 0x40u);
+}
+
 TE_HD void play_rt(const Ctx& cx, Player& q, int r, int t) {
 #if defined(TE_ABLATE) && (TE_ABLATE & 2)
     lock_piece(cx, q); return;                       // diagnostic build: no rotations / slides
@@ -1029,7 +1084,8 @@ TE_HD void play_rt(const Ctx& cx, Player& q, int r, int t) {
     const Shapes4 sh = shapes_of_kind(cx, q.kind);
     const Shapes4 dw = drop_words_of_kind(cx, q.kind);
     if (q.y != 0 || q.x != (NCOL - 4) / 2) TE_COUNT(PC_RT_OFF_SPAWN);
-    uint64_t band = band_window(cx, q, q.y);
+    RowsFrom rows = rows_from(cx, q, q.y);
+    uint64_t band = band_of_rows(rows);
     uint32_t win = band_win32(band, q.x);            // band positions x .. x+4 (piece x - 2 .. x + 2), piece itself at k = 2
     const bool fit1 = (((pick4(sh, q.rot + 1) & 0xFFFFu) << 8) & win) == 0;
     const bool fit2 = (((pick4(sh, q.rot + 2) & 0xFFFFu) << 8) & win) == 0;
@@ -1050,7 +1106,7 @@ TE_HD void play_rt(const Ctx& cx, Player& q, int r, int t) {
         while (left > 0) {
             const int nr = (q.rot + 1) & 3;
             const uint32_t s1 = pick4(sh, nr) & 0xFFFFu;        // does not fit at (x, y): the 7 offsets in the reference's order
-            const uint64_t b1 = band_window(cx, q, q.y + 1);
+            const uint64_t b1 = band_one_down(band, rows);
             const uint32_t win1 = band_win32(b1, q.x);
             const uint32_t sA = s1, sB = s1 << 4, sC = s1 << 8, sD = s1 << 12, sE = s1 << 16;   // dx = -2 .. +2
             // all seven tests, then a priority select (no nested divergent branches)
@@ -1069,7 +1125,10 @@ TE_HD void play_rt(const Ctx& cx, Player& q, int r, int t) {
             TE_COUNT(kicks == 1 ? PC_KICK : (kicks == 2 ? PC_KICK_2ND : PC_KICK_3RD));
             if (dy) TE_COUNT(PC_KICK_DOWN);
             q.rot = nr; q.x += dx; q.y += dy;
-            if (dy) band = b1;
+            if (dy) {
+                band = b1;
+                for (int c = 0; c < NCOL; c++) rows.v[c] >>= 1;       // rows from y + 1 down (the floor keeps a bit below bit 31: H - y <= 31)
+            }
             left--;
             if (left > 0) {                                     // rotations that fit in place at the new position
                 win = band_win32(band, q.x);
@@ -1092,7 +1151,7 @@ TE_HD void play_rt(const Ctx& cx, Player& q, int r, int t) {
     q.x = xs - 2;
     TE_STAMP(12);
     // gamePlay.cpp:48-52 hd_make
-    q.y += drop_distance_bytes(cx, q, shape, pick4(dw, q.rot));
+    q.y += drop_distance_rows(cx, q, rows, shape, pick4(dw, q.rot));
     TE_STAMP(13);
     stamp(cx, q, shape);
     q.drop_time = q.time_ms;
@@ -1459,7 +1518,8 @@ TE_HD void reset_split(const Ctx& cx, Game<1>& g, uint32_t seed16) {
 }
 
 // seed16 = (12345 + 7919 i + 104729 e) mod 65536
-TE_HD uint32_t episode_seed(uint32_t game, uint32_t episode) { return (12345u + 7919u * game + 104729u * episode) & 0xFFFFu; }
+// (only the low 16 bits of the sum count, so the low 16 bits of game and episode do: two full-rate 24-bit multiplies)
+TE_HD uint32_t episode_seed(uint32_t game, uint32_t episode) { return (12345u + mul24(7919u, game & 0xFFFFu) + mul24(104729u & 0xFFFFu, episode & 0xFFFFu)) & 0xFFFFu; }
 
 // Philox4x32-10 (Salmon et al., SC'11), key (k0, 0), counter (c0, c1, c2, 0): the synthetic policy
 TE_HD void philox4x32_10(uint32_t k0, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t out[4]) {

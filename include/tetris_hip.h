@@ -207,7 +207,8 @@ int tetris_enumerate_drops_dev_ex(tetris_batch *b, const int32_t *d_idx, int n, 
 /* replaces: PythonHandle.get_actions(player); masks[player].action (PythonHandle.cpp:190, TestField.cpp:64-415):
  * the reference's exact ordered key lists of the "place_block" action type — every (x, rotation) drop plus the
  * tuck / spin placements found by its backwards search — for the current piece of player[i] (NULL = player 0).
- * count[n] = number of lists; list k of game i: lens[i][k] keys at keys[i][k][0..].  Python applies
+ * count[n] = number of lists; list k of game i: lens[i][k] keys at keys[i][k][0..]; masks[player].mask of the reference after
+ * this call is count[i] ones (TestField.cpp:113-133 pushes a 1 beside every list).  Python applies
  * data_types.action_list (dedupe, null-move policy) on top.  TETRIS_E_ARG if a game has more than max_lists lists
  * or a list more than max_keys keys (64 / 48 always suffice for 10-wide boards up to 31 rows).                   */
 int tetris_get_actions(tetris_batch *b, const int32_t *idx, int n, const uint8_t *player, uint8_t *keys,

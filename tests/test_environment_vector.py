@@ -387,3 +387,13 @@ def test_action_batch_and_action_lists_step_alike_and_untouched_states_restore(k
     envs[0].perform_action(edt.action_batch.from_rt(np.zeros(n, int), np.zeros(n, int)), player=1)
     envs[0].set(looked)
     assert np.array_equal(envs[0].backend.snapshot(), envs[1].backend.snapshot())
+
+
+def test_get_actions_with_masks_is_one_flag_per_list():
+    """PythonHandle.masks[p].mask after get_actions is a vector of ones as long as masks[p].action (TestField.cpp:113-133; probed
+    against the compiled reference, 200 calls)."""
+    b = engines.make("harness", 4, 2, seeds=np.arange(4))
+    lists, masks = b.get_actions(player=1, with_masks=True)
+    assert [len(m) for m in masks] == [len(l) for l in lists] and all(set(m) == {1} for m in masks)
+    one, m1 = b.get_actions(2, player=0, with_masks=True)
+    assert m1 == [1] * len(one) and len(one) > 5
