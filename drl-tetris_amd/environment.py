@@ -21,6 +21,11 @@ import numpy as np
 
 from . import data_types, state_processors
 from .capi import TetrisBatch
+
+try:                                   # C helper that packs a Python list of actions (csrc/fastpack.c; built by __graft_entry__.build())
+    from . import _fastpack
+except ImportError:                    # not built: the Python packer below does the same, ~5x slower
+    _fastpack = None
 from .data_types import action, action_batch, action_list, lazy_list, maingoal_reward, null_action, snapshot_batch, state
 
 DEFAULT_SETTINGS = {          # the env-relevant keys of experiments/presets.py:123-182
@@ -165,6 +170,12 @@ class tetris_environment_vector:
             keys = np.zeros((n, self.n_players, max(1, actions.keys.shape[1])), np.uint8)
             keys[rows, who] = actions.keys
             lens[rows, who] = actions.lens
+            return keys, lens
+        if _fastpack is not None and type(actions) is list:
+            width = _fastpack.max_len(actions, action)              # (TypeError for an element that is not an `action`)
+            assert width <= 255, "an action may hold at most 255 keys (uint8 length on the device)"
+            keys = np.zeros((n, self.n_players, max(1, width)), np.uint8)
+            _fastpack.fill(actions, who.ctypes.data, keys.ctypes.data, lens.ctypes.data, n, self.n_players, keys.shape[2])
             return keys, lens
         assert set(map(type, actions)) <= {action}, "perform_action(action a, int p) was called with an action that is not of type `action`"
         packed = list(map(bytes, actions))          # (a key outside 0..255 raises here)

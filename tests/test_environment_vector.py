@@ -397,3 +397,25 @@ def test_get_actions_with_masks_is_one_flag_per_list():
     assert [len(m) for m in masks] == [len(l) for l in lists] and all(set(m) == {1} for m in masks)
     one, m1 = b.get_actions(2, player=0, with_masks=True)
     assert m1 == [1] * len(one) and len(one) > 5
+
+
+def test_c_packer_and_python_packer_agree():
+    """drl-tetris_amd/_fastpack (csrc/fastpack.c) against the pure-Python packer of environment._pack: same arrays, same errors."""
+    env_mod = __import__("importlib").import_module("drl-tetris_amd.environment")
+    edt = __import__("importlib").import_module("drl-tetris_amd.data_types")
+    assert env_mod._fastpack is not None, "build it: python -c 'import __graft_entry__ as g; g.build()'"
+    pkg, _, env = _make_env("harness", 300, {"n_players": 2, "game_size": [20, 10], "seed_source": _Clock()})
+    rng = np.random.default_rng(9)
+    acts = [edt.action(rng.integers(0, 11, int(rng.integers(0, 40))).tolist()) for _ in range(300)]
+    who = rng.integers(0, 2, 300)
+    fast = env._pack(acts, who, 300)
+    keep, env_mod._fastpack = env_mod._fastpack, None
+    try:
+        slow = env._pack(acts, who, 300)
+    finally:
+        env_mod._fastpack = keep
+    assert np.array_equal(fast[0], slow[0]) and np.array_equal(fast[1], slow[1]) and fast[0].shape == slow[0].shape
+    with pytest.raises(TypeError):
+        env._pack(acts[:-1] + [[7]], who, 300)             # a plain list is not an `action`
+    with pytest.raises(ValueError):
+        env._pack(acts[:-1] + [edt.action([256])], who, 300)
