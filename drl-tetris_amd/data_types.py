@@ -183,12 +183,20 @@ class snapshot_batch:
     def __len__(self):
         return len(self.blob)
 
+    def state_dicts(self, parameters):
+        """the built-in `state_dict` processor for every game and player of the batch (state_processors.state_dict_batch), cached"""
+        if getattr(self, "_dicts_key", None) is not parameters:       # (a processor's parameter list is one object for its lifetime)
+            from . import state_processors
+            self._dicts, self._dicts_key = state_processors.state_dict_batch(self, parameters), parameters
+        return self._dicts
+
     def views(self):
         if self._views is None:
             P, H, nw = self.n_players, self.height, self.nw
             boards = self.blob[:, layout.NGWORDS:].reshape(len(self.blob), P, nw)
-            rows = np.arange(H, dtype=np.uint32)[:, None]
-            bit = lambda cols: ((cols[:, :, None, :] >> rows) & np.uint32(1)).astype(np.uint8)        # [n,P,10] -> [n,P,H,10]
+            def bit(cols):                           # column words [n,P,10] -> cells [n,P,H,10]: bit y of column c = cell (y, c)
+                b = np.unpackbits(np.ascontiguousarray(cols).view(np.uint8).reshape(len(cols), P, layout.NCOL, 4), axis=3, bitorder="little")
+                return np.ascontiguousarray(b[:, :, :, :H].transpose(0, 1, 3, 2))
             field = bit(boards[:, :, layout.W_COL0:layout.W_COL0 + layout.NCOL])
             if nw > layout.NWORDS:                       # colour planes: cell value = 1 + 3-bit plane value on occupied squares
                 t0 = layout.NWORDS
@@ -349,11 +357,25 @@ class state:
             return list(range(*idx.indices(len(self))))
         return list(idx) if hasattr(idx, "__iter__") else None
 
+    def _process(self, p):
+        # the built-in state_dict of a state that still is a view into its snapshot batch: from the batch's arrays (all games at
+        # once, the first time any is asked for); anything else — a custom processor, a state whose views were written to —
+        # through the processor itself
+        proc = self.state_processor
+        if getattr(proc.func, "__name__", "") == "state_dict":
+            pending = self.__dict__.get("_pending")
+            if pending is None:
+                b = self.__dict__.get("backend_state")
+                pending = (b._batch, b._j) if b is not None and b._states is None else None
+            if pending is not None and isinstance(p, (int, np.integer)) and 0 <= p < pending[0].n_players:
+                return pending[0].state_dicts(proc.parameters).item(pending[1], int(p))
+        return proc(self.backend_state, p)
+
     def __getitem__(self, idx):
         players = self._players(idx)
         if players is None:
-            return self.state_processor(self.backend_state, idx)
-        return [self.state_processor(self.backend_state, p) for p in players]
+            return self._process(idx)
+        return [self._process(p) for p in players]
 
     def __len__(self):
         return self.backend_state.n_players
