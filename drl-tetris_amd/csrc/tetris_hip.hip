@@ -4,6 +4,7 @@
 // tetris_engine.h.  Launch geometry: 256-thread workgroups (one wave per SIMD of a CU); 64k games
 // = 256 workgroups = one per CU, so the kernel is latency/issue bound, not occupancy bound.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <math.h>
 #include <stdio.h>
@@ -2014,7 +2015,13 @@ int tetris_rollout_launch(tetris_batch* b, int launches, int steps_per_launch, u
         tetris_batch* b; bool armed;
         ~GoGuard() { if (armed) ((volatile uint32_t*)b->flags)[F_GO] = 1; }
     } go_guard{b, prequeue};
-    HIP_TRY(hipEventRecord(b->ev0, chained ? b->chain_stream[0] : home));
+    // Chained calls attach their events to the kernels themselves (hipExtLaunchKernel: the first launch carries the start event,
+    // the last launch of every stream its end event) instead of recording them as packets of their own in front of and behind the
+    // launches: a marker packet ahead of the first kernel and one behind the last cost the driver's 20-launch region a few
+    // microseconds each.  TETRIS_EXT_EVENTS=0: plain event records.
+    static const bool ext_events = [] { const char* e = getenv("TETRIS_EXT_EVENTS"); return !(e && e[0] == '0'); }();
+    const bool attach = chained && ext_events;
+    if (!attach) HIP_TRY(hipEventRecord(b->ev0, chained ? b->chain_stream[0] : home));
     static const bool timing = getenv("TETRIS_TIMING") != nullptr;         // debug aid: host-side cost of this loop on stderr
     const auto t_begin = std::chrono::steady_clock::now();
     double gate_s = 0.0;
@@ -2028,8 +2035,12 @@ int tetris_rollout_launch(tetris_batch* b, int launches, int steps_per_launch, u
         a.first_step = first_step + (uint64_t)l * (uint64_t)steps_per_launch;
         if (chained) {
             a.chain = b->d_chain; a.epoch = ++b->chain_epoch; a.chain_spin_limit = b->chain_spin_limit;
-            if (b->P == 1) hipLaunchKernelGGL((k_chain<1>), dim3((unsigned)((b->N + CHAIN_LANES - 1) / CHAIN_LANES)), dim3(64), 0, b->stream, a);
-            else hipLaunchKernelGGL((k_duo<M_ROLLOUT, true>), dim3((unsigned)((b->N + 31) / 32)), dim3(64), 0, b->stream, a);
+            // (attached events: start of the call's first kernel; end of the last kernel of each stream — the call's last launch
+            // carries the timing event ev1, the last launches of the other streams their join events)
+            hipEvent_t start_ev = (attach && l == 0) ? b->ev0 : nullptr, stop_ev = nullptr;
+            if (attach && l >= launches - b->chain_depth) stop_ev = l == launches - 1 ? b->ev1 : b->chain_ev[l % b->chain_depth];
+            if (b->P == 1) hipExtLaunchKernelGGL((k_chain<1>), dim3((unsigned)((b->N + CHAIN_LANES - 1) / CHAIN_LANES)), dim3(64), 0, b->stream, start_ev, stop_ev, 0, a);
+            else hipExtLaunchKernelGGL((k_duo<M_ROLLOUT, true>), dim3((unsigned)((b->N + 31) / 32)), dim3(64), 0, b->stream, start_ev, stop_ev, 0, a);
             const hipError_t le = hipGetLastError();
             if (le != hipSuccess) {
                 // this launch does not exist: without it no wave could ever publish its epoch, so the numbering steps back
@@ -2047,9 +2058,11 @@ int tetris_rollout_launch(tetris_batch* b, int launches, int steps_per_launch, u
     // the events for whatever comes next.
     hipStream_t const last = b->stream;
     const int used = chained ? (launches < b->chain_depth ? launches : b->chain_depth) : 0;
-    HIP_TRY(hipEventRecord(b->ev1, last));
-    for (int k = 0; k < used; k++)
-        if (b->chain_stream[k] != last) HIP_TRY(hipEventRecord(b->chain_ev[k], b->chain_stream[k]));
+    if (!attach) {
+        HIP_TRY(hipEventRecord(b->ev1, last));
+        for (int k = 0; k < used; k++)
+            if (b->chain_stream[k] != last) HIP_TRY(hipEventRecord(b->chain_ev[k], b->chain_stream[k]));
+    }
     for (int k = 0; k < used; k++) HIP_TRY(hipStreamWaitEvent(home, b->chain_stream[k] != last ? b->chain_ev[k] : b->ev1, 0));
     b->stream = home;
     if (prequeue) { ((volatile uint32_t*)b->flags)[F_GO] = 1; go_guard.armed = false; }      // everything is queued: go
