@@ -73,7 +73,9 @@ __global__ __launch_bounds__(64) void k_chain(KArgs a) {
     __builtin_amdgcn_wave_barrier();
     if (active) game_run<P, M_ROLLOUT, false, MEM_AGENT>(a, i, s_shapes, g, cnt);
     TE_STAMP_CHAIN(a.epoch, 4);
+#if !defined(TE_EXPERIMENT_NO_ACK)      // (timing experiment only, results INVALID: what would a hand-off that does not wait for the store acknowledgements gain?)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every store (and counter atomic) of this wave has been acknowledged
+#endif
     TE_STAMP_CHAIN(a.epoch, 5);
     if (lane == 0) st_agent(a.chain + (size_t)wave * CHAIN_STRIDE, a.epoch);
     TE_STAMP_CHAIN(a.epoch, 6);
