@@ -271,6 +271,8 @@ int tetris_debug_stall(tetris_batch *b, int which, int microseconds, int percent
  *   TETRIS_CHAIN_PRIO=0 the chain streams are created with equal priorities (they may then share a hardware queue)
  *   TETRIS_CHAIN_DEPTH=1..3  at most that many chained launches in flight; 1 = the chained kernel on one stream, i.e. dispatches
  *                       serialised by the stream (what per-dispatch PMC counters need: profiles/pmc_summary.py)
+ *   TETRIS_EXT_EVENTS=0 chained calls record their timing / join events as packets of their own instead of attaching them to the
+ *                       first and last kernels (hipExtLaunchKernel, the default)
  *   TETRIS_TIMING=1     tetris_rollout_launch prints its host-side costs (enqueue per launch, gate waits, until drained) to stderr */
 /* 1 if tetris_rollout_launch / tetris_rollout_random would chain launches of `steps_per_launch` steps on this batch, 0 if not
  * (switched off — by the caller or by a fall-back —, caller-owned stream, split or colour batch, or not even two launches fit
