@@ -75,3 +75,16 @@ def test_a_co_tenant_that_holds_most_wave_slots_costs_time_not_results():
         step += 64
         assert eng.take_errors() in (0, FELL_BACK)
     _check(eng, ref, n, total, step)
+
+
+def test_test_aid_and_knob_validate_their_arguments():
+    pkg = __import__("__graft_entry__").package()
+    eng = engines.make("hip", 256, 1, seeds=np.arange(256))
+    for bad in ((4, 10, 0), (-2, 10, 0), (0, -1, 0), (0, 3000000, 0), (-1, 10, 101)):
+        with pytest.raises(pkg.TetrisError):
+            eng.debug_stall(*bad)
+    eng.set_chain_spin_limit(123)
+    eng.set_chain_spin_limit(0)                 # back to the default
+    eng.debug_stall(3, 100)                     # the batch's own stream: just a short idle kernel
+    c, _ = eng.rollout_random(5, 1)
+    assert int(c[0]) == 5 * 256 and eng.take_errors() == 0
