@@ -59,6 +59,7 @@ _SIGNATURES = {
     "tetris_rollout_is_chained": (C.c_int, [C.c_void_p, C.c_int]),
     "tetris_set_chain_spin_limit": (C.c_int, [C.c_void_p, C.c_uint32]),
     "tetris_debug_stall": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "tetris_debug_clock_khz": (C.c_int, [C.c_void_p, C.c_void_p]),
     "tetris_reset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "tetris_make_actions": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
     "tetris_finish_actions": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -385,6 +386,12 @@ class TetrisBatch:
         """Test aid (include/tetris_hip.h: tetris_debug_stall): idle kernel on chain stream 0..2, on the batch's stream (3) or,
         which = -1, holding `percent` % of the device's wave slots on a stream of its own."""
         self._check(self.lib.tetris_debug_stall(self._h, int(which), int(microseconds), int(percent)))
+
+    def clock_mhz(self):
+        """Measurement aid: the GPU's shader clock of the moment (tetris_debug_clock_khz)."""
+        khz = C.c_int(0)
+        self._check(self.lib.tetris_debug_clock_khz(self._h, C.byref(khz)))
+        return khz.value / 1000.0
 
     def rollout_is_chained(self, steps_per_launch=1):
         rc = self.lib.tetris_rollout_is_chained(self._h, int(steps_per_launch))

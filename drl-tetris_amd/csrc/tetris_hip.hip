@@ -12,7 +12,9 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <mutex>
+#include <thread>
 #include <new>
 #include <chrono>
 #include <string>
@@ -91,6 +93,16 @@ __global__ void k_blocker(const uint32_t* go, unsigned long long ticks) {
         if (go && __hip_atomic_load(go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) break;
         __builtin_amdgcn_s_sleep(32);
     }
+}
+
+// Measurement aid (tetris_debug_clock_khz): shader clock of the moment, from the ratio of the shader cycle counter to the constant
+// 100 MHz real-time counter over ~`ticks` of the latter, by one wave
+__global__ void k_clock_probe(unsigned long long ticks, unsigned long long* out) {
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime(), c0 = __builtin_amdgcn_s_memtime();
+    unsigned long long r1 = r0;
+    while (r1 - r0 < ticks) { __builtin_amdgcn_s_sleep(4); r1 = __builtin_amdgcn_s_memrealtime(); }
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+    if (threadIdx.x == 0) { out[0] = c1 - c0; out[1] = r1 - r0; }
 }
 
 // Sums the per-game cumulative rollout counters (G_STEPS, G_EPISODE, G_LINES, G_SENT): run once before and once
@@ -757,6 +769,13 @@ struct Stage {
     }
 };
 
+// 120: the host may be 241 launches (~1 ms of GPU work at 64k boards) ahead of what it has seen finish.  With 32 (round 2: 65
+// launches, 0.26 ms) a host thread that loses its core for a fraction of a millisecond — other tenants' jobs share the box's CPUs —
+// starves the GPU: 8192-launch runs measured 4.2-5.1 us per launch in bad minutes against 4.02-4.21 with 120, and 4.02 either way in
+// good ones (profiles/r03/gate_depth_ab.txt).  The low-water margin of the RNG tables is sized from it (< one chunk of 624 draws).
+#ifndef TE_GATE_GROUP
+#define TE_GATE_GROUP 120
+#endif
 struct tetris_batch {
     int device = 0, N = 0, P = 0, H = 0;
     int stride = 0;                      // games per row of the state arrays: N + padding (see create_impl)
@@ -768,7 +787,7 @@ struct tetris_batch {
     unsigned long long* d_counters = nullptr;
     unsigned long long* h_counters = nullptr;   // pinned [8]
     Tables* tab = nullptr;
-    uint32_t margin = 192;               // low-water mark of the RNG tables (draws); covers the launches in flight (gate below)
+    uint32_t margin = 2 * (2 * TE_GATE_GROUP + 2) + 16;      // low-water mark of the RNG tables (draws); covers the launches in flight (gate below)
     uint32_t game_offset = 0;
     int split = 0, side = 0;
     int tint = 0, nw = NWORDS;           // colour planes tracked; words per player-board
@@ -778,6 +797,7 @@ struct tetris_batch {
     // chained launches (k_chain): two extra streams, one epoch word per wave, the number of the last chained launch
     hipStream_t chain_stream[CHAIN_STREAMS] = {};
     hipEvent_t chain_ev[CHAIN_STREAMS + 1] = {};      // [k]: end of chain stream k's last launch (join); [CHAIN_STREAMS]: fork from the batch's stream
+    hipEvent_t worker_gate_ev[CHAIN_STREAMS][2] = {}; // run-ahead gates of the per-stream enqueue threads (tetris_rollout_launch)
     uint32_t* d_chain = nullptr;
     uint32_t chain_epoch = 0;
     int use_chain = 1;                   // TETRIS_NO_CHAIN=1 in the environment: every rollout launch on the batch's one stream
@@ -802,7 +822,8 @@ struct tetris_batch {
     int gate_pending[2] = {0, 0};        // event has been recorded and not waited for
     Stage s_idx, s_in0, s_in1, s_in2, s_out0, s_out1, s_out2, s_big, s_act0, s_act1, s_act2;
 };
-static constexpr int GATE_GROUP = 32;
+// (TETRIS_GATE_GROUP in the environment: experiment knob, 8..120)
+static const int GATE_GROUP = [] { const char* e = getenv("TETRIS_GATE_GROUP"); const int v = e ? atoi(e) : TE_GATE_GROUP; return v < 8 ? 8 : (v > 120 ? 120 : v); }();
 
 static Geo geo_of_batch(tetris_batch* b) {
     Geo g = {b->d_state, b->d_gstate ? b->d_gstate : b->d_state, (size_t)b->N, b->P, b->nw, (size_t)b->stride};
@@ -927,11 +948,18 @@ static int service_flags(tetris_batch* b) {
 }
 
 // One more asynchronous launch is about to be enqueued: bound the run-ahead (see tetris_batch) and service the flags.
-static int gate_launch(tetris_batch* b, int group = GATE_GROUP) {
+static int gate_launch(tetris_batch* b, int group) {
     if (b->gate_count >= group) {
         const int k = b->gate_slot;
         if (b->gate_pending[k]) {                               // the group before the previous one must have finished
-            HIP_TRY(hipEventSynchronize(b->gate_ev[k]));
+            // polled, not slept on: a thread blocked in hipEventSynchronize is woken through an interrupt — 10-20 us late at
+            // best, milliseconds when the scheduler has given its core away meanwhile — and the GPU has only the launches of two
+            // groups (~0.26 ms) to live on; TETRIS_GATE_BLOCK=1: the blocking wait
+            static const bool block = [] { const char* e = getenv("TETRIS_GATE_BLOCK"); return e && e[0] == '1'; }();
+            hipError_t qe = hipErrorNotReady;
+            for (int spin = 0; !block && spin < 2000000 && qe == hipErrorNotReady; spin++) qe = hipEventQuery(b->gate_ev[k]);
+            if (qe == hipErrorNotReady) qe = hipEventSynchronize(b->gate_ev[k]);
+            HIP_TRY(qe);
             b->gate_pending[k] = 0;
         }
         HIP_TRY(hipEventRecord(b->gate_ev[k], b->stream));
@@ -1067,6 +1095,7 @@ int tetris_destroy(tetris_batch* b) {
     if (b->h_counters) (void)hipHostFree(b->h_counters);
     for (hipEvent_t e : b->gate_ev) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : b->chain_ev) if (e) (void)hipEventDestroy(e);
+    for (auto& pair : b->worker_gate_ev) for (hipEvent_t e : pair) if (e) (void)hipEventDestroy(e);
     for (hipStream_t st : b->chain_stream) if (st) (void)hipStreamDestroy(st);
     (void)hipFree(b->d_chain);
     free(b->h_chain);
@@ -1137,6 +1166,7 @@ static int create_impl(tetris_batch** out, int n_games, int n_players, int heigh
         }
     }
     for (int k = 0; k < CHAIN_STREAMS + 1; k++) CREATE_TRY(hipEventCreateWithFlags(&b->chain_ev[k], hipEventDisableTiming));
+    for (int k = 0; k < CHAIN_STREAMS; k++) for (int j = 0; j < 2; j++) CREATE_TRY(hipEventCreateWithFlags(&b->worker_gate_ev[k][j], hipEventDisableTiming));
     {
         const size_t chain_bytes = (((size_t)n_games + 15) / 16) * sizeof(uint32_t) * CHAIN_STRIDE;       // (one word per wave; at least 16 games per wave)
         CREATE_TRY(hipMalloc((void**)&b->d_chain, chain_bytes));
@@ -1210,6 +1240,21 @@ int tetris_debug_stall(tetris_batch* b, int which, int microseconds, int percent
         if (blocks > 0) hipLaunchKernelGGL(k_blocker, dim3((unsigned)blocks), dim3(1024), 0, b->stall_stream, (const uint32_t*)nullptr, ticks);
     }
     HIP_TRY(hipGetLastError());
+    return TETRIS_OK;
+}
+
+// Measurement aid: the GPU's shader clock right now, in kHz (a 50 us probe kernel on the batch's stream; synchronous).  The
+// chained period follows it: DESIGN.md, section 6.
+int tetris_debug_clock_khz(tetris_batch* b, int* khz) {
+    int rc = check_batch(b);
+    if (rc) return rc;
+    if (!khz) return fail(TETRIS_E_ARG, "khz is NULL");
+    HIP_TRY(hipMemsetAsync(b->d_counters + 4, 0, 2 * sizeof(unsigned long long), b->stream));
+    hipLaunchKernelGGL(k_clock_probe, dim3(1), dim3(64), 0, b->stream, 5000ull, b->d_counters + 4);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(b->h_counters + 4, b->d_counters + 4, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, b->stream));
+    if ((rc = finish_call(b))) return rc;
+    *khz = b->h_counters[5] ? (int)(b->h_counters[4] * 100000ull / b->h_counters[5]) : 0;
     return TETRIS_OK;
 }
 
@@ -1438,7 +1483,7 @@ int tetris_step_rt_dev_ex(tetris_batch* b, const uint8_t* d_rot, const uint8_t* 
     if (!d_rot || !d_trans) return fail(TETRIS_E_ARG, "rot/trans are NULL");
     if (flags & ~TETRIS_STEP_AUTO_RESET) return fail(TETRIS_E_ARG, "unknown flag");
     if ((flags & TETRIS_STEP_AUTO_RESET) && b->split) return fail(TETRIS_E_ARG, "auto-reset is not available on split batches");
-    if ((rc = gate_launch(b))) return rc;
+    if ((rc = gate_launch(b, GATE_GROUP))) return rc;
     KArgs a = base_args(b, b->N, nullptr);
     a.rot = d_rot; a.trans = d_trans; a.player = d_player; a.ms = ms;
     a.done = d_done; a.lines = d_lines; a.dead = d_dead;
@@ -1460,7 +1505,7 @@ int tetris_step_rt_observe_dev(tetris_batch* b, const uint8_t* d_rot, const uint
         if ((rc = tetris_step_rt_dev_ex(b, d_rot, d_trans, d_player, ms, d_done, d_lines, d_dead, flags))) return rc;
         return tetris_observe_packed_dev(b, nullptr, b->N, d_next_player, d_visual, d_vector, d_piece);
     }
-    if ((rc = gate_launch(b))) return rc;
+    if ((rc = gate_launch(b, GATE_GROUP))) return rc;
     KArgs a = base_args(b, b->N, nullptr);
     a.rot = d_rot; a.trans = d_trans; a.player = d_player; a.ms = ms;
     a.done = d_done; a.lines = d_lines; a.dead = d_dead;
@@ -1499,7 +1544,7 @@ int tetris_reset_dev(tetris_batch* b, const uint8_t* d_mask, const int16_t* d_se
     int rc = check_batch(b);
     if (rc) return rc;
     if (b->split) return fail(TETRIS_E_ARG, "tetris_reset_dev is not available on split batches");
-    if ((rc = gate_launch(b))) return rc;
+    if ((rc = gate_launch(b, GATE_GROUP))) return rc;
     KArgs a = base_args(b, b->N, nullptr);
     a.mask = d_mask; a.seeds = d_seeds;
     return d_seeds ? launch_game<M_RESET>(b, a) : launch_game<M_RESET_SCHED>(b, a);
@@ -1928,8 +1973,8 @@ int tetris_rollout_launch(tetris_batch* b, int launches, int steps_per_launch, u
         tetris_batch* b; uint32_t saved;
         ~MarginGuard() { b->margin = saved; }
     } margin_guard{b, saved_margin};
-    int group = steps_per_launch ? 64 / steps_per_launch : GATE_GROUP;       // fused launches: fewer of them in flight
-    group = group < 1 ? 1 : (group > GATE_GROUP ? GATE_GROUP : group);
+    int group = steps_per_launch ? GATE_GROUP / steps_per_launch : GATE_GROUP;       // fused launches: fewer of them in flight
+    group = group < 1 ? 1 : group;
     const uint32_t need = (uint32_t)(2 * steps_per_launch * (2 * group + 2) + 16);
     if (b->margin < need) b->margin = need;
     // batches on their own stream: chained launches (k_chain / k_duo<.., true>) — consecutive launches rotate over CHAIN_STREAMS
@@ -2027,7 +2072,19 @@ int tetris_rollout_launch(tetris_batch* b, int launches, int steps_per_launch, u
     static const bool timing = getenv("TETRIS_TIMING") != nullptr;         // debug aid: host-side cost of this loop on stderr
     const auto t_begin = std::chrono::steady_clock::now();
     double gate_s = 0.0;
-    for (int l = 0; l < launches; l++) {
+    // Long chained calls are enqueued by one host thread PER CHAIN STREAM.  A launch costs the host 2.7-4.0 us depending on the
+    // process (the core its thread sits on, what the box's other tenants do) and the GPU needs one every 4.03 us: in the slower
+    // processes one thread could not keep up and the rollout ran at the host's pace, 4.2-4.6 us per launch
+    // (profiles/r03/host_pace.txt).  Every stream's launches are independent of the others' on the host side — epoch and step of
+    // launch l follow from l — so each thread enqueues every depth-th launch on its own stream with its own run-ahead gate; this
+    // thread keeps looking at the flag words (RNG-table extensions) meanwhile.  TETRIS_ENQUEUE_THREADS_MIN=0: never; n: from n launches.
+    static const int thread_min = [] { const char* e = getenv("TETRIS_ENQUEUE_THREADS_MIN"); return e ? atoi(e) : 256; }();
+    const bool threaded = chained && !prequeue && thread_min > 0 && launches >= thread_min;
+    // (this thread enqueues the first launches of every stream itself, so the GPU has work while the other threads start up,
+    // and then serves stream 0)
+    const int prefix = threaded ? std::min(launches, 8 * b->chain_depth) : launches;
+    const uint32_t call_epoch0 = b->chain_epoch;
+    for (int l = 0; l < prefix; l++) {
         if (chained) { b->stream = b->chain_stream[l % b->chain_depth]; b->chain_pending = true; }
         const auto t_gate = std::chrono::steady_clock::now();
         if ((rc = gate_launch(b, group))) return rc;
@@ -2053,12 +2110,72 @@ int tetris_rollout_launch(tetris_batch* b, int launches, int steps_per_launch, u
         } else if ((rc = launch_game<M_ROLLOUT>(b, a)))
             return rc;
     }
+    if (threaded && prefix < launches) {
+        const int depth = b->chain_depth, wgroup = std::max(8, group / depth);
+        const uint32_t epoch0 = call_epoch0;
+        b->chain_epoch = epoch0 + (uint32_t)launches;           // (a launch that fails to be enqueued leaves waves waiting: they give up, chain_recover finishes the call)
+        b->chain_pending = true;
+        b->stream = home;
+        std::atomic<int> failed{0}, finished{0};
+        hipError_t worker_err[CHAIN_STREAMS] = {};
+        int flag_rc = TETRIS_OK;
+        const bool main_works_flag = [] { const char* e = getenv("TETRIS_ENQUEUE_MAIN_WORKS"); return !(e && e[0] == '0'); }();
+        auto worker = [&](int k) {
+            hipError_t err = hipSetDevice(b->device);
+            int mine = 0, slot = 0;
+            bool pending[2] = {false, false};
+            hipStream_t const st = b->chain_stream[k];
+            for (int l = prefix + k; l < launches && err == hipSuccess && !failed.load(std::memory_order_relaxed); l += depth) {
+                if (k == 0 && main_works_flag && !flag_rc && (flag_rc = service_flags(b))) { failed.store(1); break; }      // (this thread: the flag words, as ever)
+                if (mine >= wgroup) {                            // at most 2 * wgroup + 1 launches of this stream in flight
+                    if (pending[slot]) {
+                        hipError_t qe = hipErrorNotReady;
+                        for (int spin = 0; spin < 2000000 && qe == hipErrorNotReady; spin++) qe = hipEventQuery(b->worker_gate_ev[k][slot]);
+                        if (qe == hipErrorNotReady) qe = hipEventSynchronize(b->worker_gate_ev[k][slot]);
+                        if (qe != hipSuccess) { err = qe; break; }
+                    }
+                    if ((err = hipEventRecord(b->worker_gate_ev[k][slot], st)) != hipSuccess) break;
+                    pending[slot] = true; slot ^= 1; mine = 0;
+                }
+                mine++;
+                KArgs a = base_args(b, b->N, nullptr);           // (table pointer and size under the tables' mutex: this thread may be extending them)
+                a.ms = ms; a.steps = steps_per_launch; a.policy_seed = policy_seed;
+                a.first_step = first_step + (uint64_t)l * (uint64_t)steps_per_launch;
+                a.chain = b->d_chain; a.epoch = epoch0 + (uint32_t)l + 1u; a.chain_spin_limit = b->chain_spin_limit;
+                hipEvent_t start_ev = (attach && l == 0) ? b->ev0 : nullptr, stop_ev = nullptr;
+                if (attach && l >= launches - depth) stop_ev = l == launches - 1 ? b->ev1 : b->chain_ev[k];
+                if (b->P == 1) hipExtLaunchKernelGGL((k_chain<1>), dim3((unsigned)((b->N + CHAIN_LANES - 1) / CHAIN_LANES)), dim3(64), 0, st, start_ev, stop_ev, 0, a);
+                else hipExtLaunchKernelGGL((k_duo<M_ROLLOUT, true>), dim3((unsigned)((b->N + 31) / 32)), dim3(64), 0, st, start_ev, stop_ev, 0, a);
+                err = hipGetLastError();
+            }
+            if (err != hipSuccess) { worker_err[k] = err; failed.store(1); }
+            finished.fetch_add(1);
+        };
+        std::thread th[CHAIN_STREAMS];
+        bool inline_k[CHAIN_STREAMS] = {};
+        // (TETRIS_ENQUEUE_MAIN_WORKS=0, experiment knob: a thread for stream 0 too, this one only watches the flag words — same
+        // periods, a few more outliers: profiles/r03/host_pace.txt)
+        static const bool main_works = [] { const char* e = getenv("TETRIS_ENQUEUE_MAIN_WORKS"); return !(e && e[0] == '0'); }();
+        for (int k = main_works ? 1 : 0; k < depth; k++) {
+            try { th[k] = std::thread(worker, k); } catch (...) { inline_k[k] = true; }      // (no thread to be had: this one does that stream too)
+        }
+        if (main_works) worker(0);
+        for (int k = 0; k < depth; k++) if (inline_k[k]) worker(k);
+        while (finished.load() < depth) {
+            if (!flag_rc && (flag_rc = service_flags(b))) failed.store(1);
+            for (int spin = 0; spin < 200 && finished.load(std::memory_order_relaxed) < depth; spin++) __builtin_ia32_pause();
+        }
+        for (int k = 0; k < depth; k++) if (th[k].joinable()) th[k].join();
+        if (flag_rc) return flag_rc;
+        for (int k = 0; k < depth; k++)
+            if (worker_err[k] != hipSuccess) return fail(TETRIS_E_HIP, std::string("chained launch (enqueue thread): ") + hipGetErrorString(worker_err[k]));
+    }
     // Every chain stream gets an event behind its last launch (the last launch's stream carries the timing event ev1); the host
     // waits for these events by polling them — an interrupt wakes a blocked thread 10-20 us late, and querying a STREAM makes the
     // runtime push a marker through its queue and wait for it, ~6 us per stream even when it is idle.  Nothing on the GPU waits
     // for another stream here (a cross-stream join costs the rollout ~15 us at its end); the batch's own stream is ordered behind
     // the events for whatever comes next.
-    hipStream_t const last = b->stream;
+    hipStream_t const last = chained ? b->chain_stream[(launches - 1) % b->chain_depth] : b->stream;
     const int used = chained ? (launches < b->chain_depth ? launches : b->chain_depth) : 0;
     if (!attach) {
         HIP_TRY(hipEventRecord(b->ev1, last));

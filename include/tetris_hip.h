@@ -135,7 +135,7 @@ int tetris_step_rt_dev(tetris_batch *b, const uint8_t *d_rot, const uint8_t *d_t
  * mod 65536 with game = global game id (tetris_set_game_offset) and episode = the game's count of resets so far;
  * d_done / d_lines / d_dead report the step as it ended, BEFORE the reset.
  * The asynchronous entry points never drain the stream: requests to extend the RNG tables reach the host through
- * flag words in pinned memory, and the host lets at most 65 launches run ahead of what it has seen of them.        */
+ * flag words in pinned memory, and the host lets at most 241 launches run ahead of what it has seen of them.       */
 #define TETRIS_STEP_AUTO_RESET 1
 int tetris_step_rt_dev_ex(tetris_batch *b, const uint8_t *d_rot, const uint8_t *d_trans,
                           const uint8_t *d_player, int ms, uint8_t *d_done, uint8_t *d_lines,
@@ -254,6 +254,8 @@ int tetris_set_chained(tetris_batch *b, int on);
 /* polls of its predecessor's epoch word after which a waiting wave of a chained launch gives up (0 = the default, 2^22);
  * one poll is an agent-scope load and a short sleep, about 0.5 us.                                                     */
 int tetris_set_chain_spin_limit(tetris_batch *b, uint32_t polls);
+/* MEASUREMENT AID: the GPU's shader clock of the moment in kHz (a 50 us probe kernel on the batch's stream; synchronous).      */
+int tetris_debug_clock_khz(tetris_batch *b, int *khz);
 /* TEST AID for the give-up path above (nothing in the product calls it): enqueues a kernel that idles for `microseconds` —
  * which = 0..2: on that one of the three chain streams, so the launches the next rollout call puts there start late;
  * which = 3: on the batch's stream; which = -1: on a stream of its own, as workgroups that hold `percent` % of the device's
@@ -273,6 +275,9 @@ int tetris_debug_stall(tetris_batch *b, int which, int microseconds, int percent
  *                       serialised by the stream (what per-dispatch PMC counters need: profiles/pmc_summary.py)
  *   TETRIS_EXT_EVENTS=0 chained calls record their timing / join events as packets of their own instead of attaching them to the
  *                       first and last kernels (hipExtLaunchKernel, the default)
+ *   TETRIS_ENQUEUE_THREADS_MIN=<n>  chained calls of at least n launches (default 256) are enqueued by one host thread per chain
+ *                       stream (a launch costs the host 2.7-4.0 us, the GPU needs one every 4.0); 0 = always one thread
+ *   TETRIS_GATE_GROUP=<n>  launches per run-ahead group (default 120: at most 241 in flight), 8..120
  *   TETRIS_TIMING=1     tetris_rollout_launch prints its host-side costs (enqueue per launch, gate waits, until drained) to stderr */
 /* 1 if tetris_rollout_launch / tetris_rollout_random would chain launches of `steps_per_launch` steps on this batch, 0 if not
  * (switched off — by the caller or by a fall-back —, caller-owned stream, split or colour batch, or not even two launches fit

@@ -251,6 +251,7 @@ int tetris_take_errors(tetris_batch* b, uint32_t* bits) {
 int tetris_set_chained(tetris_batch*, int) { return TETRIS_OK; }
 int tetris_set_chain_spin_limit(tetris_batch*, uint32_t) { return TETRIS_OK; }
 int tetris_debug_stall(tetris_batch*, int, int, int) { return TETRIS_OK; }
+int tetris_debug_clock_khz(tetris_batch*, int* khz) { if (khz) *khz = 0; return TETRIS_OK; }
 int tetris_rollout_is_chained(tetris_batch*, int) { return 0; }
 int tetris_set_game_offset(tetris_batch* b, uint64_t first) { b->game_offset = (uint32_t)first; return TETRIS_OK; }
 
