@@ -436,12 +436,24 @@ class action_batch(lazy_list):
         assert self.keys.ndim == 2 and self.lens.shape == (len(self.keys),)
         super().__init__(len(self.keys), lambda j: action(self.keys[j, : self.lens[j]].tolist()))
 
+    _rt_tables = {}
+
     @classmethod
     def from_rt(cls, rot, trans):
         """SVENton's (rotation, translation) encoding [8]*r + [2] + [3]*t + [7] (sventon_utils.py:9-13) for n envs"""
         rot, trans = np.asarray(rot, np.int64).reshape(-1), np.asarray(trans, np.int64).reshape(-1)
-        n, K = len(rot), int((rot + trans).max(initial=0)) + 2
-        col = np.arange(K)[None, :]
-        keys = np.where(col < rot[:, None], 8, np.where(col == rot[:, None], 2, np.where(col <= (rot + trans)[:, None], 3, 7)))
-        keys = np.where(col > (rot + trans + 1)[:, None], 0, keys)
-        return cls(keys.astype(np.uint8), (rot + trans + 2).astype(np.uint8))
+        if len(rot) == 0:
+            return cls(np.zeros((0, 2), np.uint8), np.zeros(0, np.uint8))
+        if rot.min() < 0 or trans.min() < 0:
+            raise ValueError("rotation and translation counts must be >= 0")
+        # the key list depends on (r, t) only: one table row per pair that can occur, then a gather for the n envs
+        n_r, n_t = int(rot.max()) + 1, int(trans.max()) + 1
+        tables = cls._rt_tables.get((n_r, n_t))
+        if tables is None:
+            r, t = np.divmod(np.arange(n_r * n_t), n_t)
+            col = np.arange(n_r + n_t)[None, :]
+            keys = np.where(col < r[:, None], 8, np.where(col == r[:, None], 2, np.where(col <= (r + t)[:, None], 3, 7)))
+            keys = np.where(col > (r + t + 1)[:, None], 0, keys).astype(np.uint8)
+            tables = cls._rt_tables[(n_r, n_t)] = (keys, (r + t + 2).astype(np.uint8))
+        code = rot * n_t + trans
+        return cls(np.take(tables[0], code, axis=0), np.take(tables[1], code))

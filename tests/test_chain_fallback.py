@@ -40,20 +40,21 @@ def test_a_late_predecessor_makes_the_call_fall_back_and_the_results_stay_exact(
     eng.set_chain_spin_limit(2000)                         # ~1 ms
     before = eng.rollout_totals()                          # (synchronises: nothing may drain the streams between the stall and the launches)
     eng.debug_stall(1, 30000)                              # the second launch of the next call (and every third after it) starts 30 ms late
-    eng.rollout_launch(50, 1, first_step=40)
+    stalled = 50 if P == 2 else 300                        # (300: the call that is enqueued by one host thread per stream)
+    eng.rollout_launch(stalled, 1, first_step=40)
     total += eng.rollout_totals() - before
     assert eng.take_errors() == FELL_BACK
     assert eng.take_errors() == 0                          # reported once
     assert not eng.rollout_is_chained(1)                   # off until switched on again
-    c, _ = eng.rollout_random(10, 1, first_step=90)        # un-chained
+    c, _ = eng.rollout_random(10, 1, first_step=40 + stalled)        # un-chained
     total += c
     eng.set_chained(True)
     eng.set_chain_spin_limit(0)
     assert eng.rollout_is_chained(1)
-    c, _ = eng.rollout_random(28, 1, first_step=100)       # chained again, from the epoch words the recovery left
+    c, _ = eng.rollout_random(28, 1, first_step=50 + stalled)        # chained again, from the epoch words the recovery left
     total += c
     assert eng.take_errors() == 0
-    _check(eng, ref, n, total, 128)
+    _check(eng, ref, n, total, 78 + stalled)
 
 
 def test_a_co_tenant_that_holds_most_wave_slots_costs_time_not_results():
