@@ -113,7 +113,9 @@ extern unsigned long long te_path_count[PC_NCOUNTERS];
 // MEM_AGENT: agent-scope (`sc1`) — the word is handed from one launch to the next WHILE both are running (chained launches,
 // tetris_hip.hip): the store is written through to memory and the load bypasses the non-coherent per-XCD L2
 // (MI355X_MICROARCH.md, inter-workgroup visibility: every store and every load of the handed-off bytes must be `sc1`).
-enum MemMode : int { MEM_STREAM = 0, MEM_AGENT = 1 };
+// MEM_AFFINE (experiment only, -DTE_EXPERIMENT_AFFINE): `sc1` loads, PLAIN stores — the line stays in the storing XCD's L2, which
+// only the same XCD may then read; measured slower than MEM_AGENT in the chained kernel (profiles/r03/handoff_experiments.txt).
+enum MemMode : int { MEM_STREAM = 0, MEM_AGENT = 1, MEM_AFFINE = 2 };
 #if defined(__HIP_DEVICE_COMPILE__)
 TE_HD uint32_t ld_agent(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 TE_HD void st_agent(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -134,22 +136,23 @@ TE_HD __amdgpu_buffer_rsrc_t te_rsrc(const void* base) {
 constexpr int TE_AUX_NT = 2, TE_AUX_SC1 = 16;     // cache-policy bits of the buffer instructions on gfx940+
 TE_HD uint32_t ldw(const uint32_t* base, uint32_t o, size_t word_off, int mem = MEM_STREAM) {
     const __amdgpu_buffer_rsrc_t r = te_rsrc(base);
-    if (mem == MEM_AGENT) return __builtin_amdgcn_raw_buffer_load_b32(r, (int)o, (int)(uint32_t)(word_off * 4u), TE_AUX_SC1);
+    if (mem == MEM_AGENT || mem == MEM_AFFINE) return __builtin_amdgcn_raw_buffer_load_b32(r, (int)o, (int)(uint32_t)(word_off * 4u), TE_AUX_SC1);
     return __builtin_amdgcn_raw_buffer_load_b32(r, (int)o, (int)(uint32_t)(word_off * 4u), TE_LD_NT ? TE_AUX_NT : 0);
 }
 TE_HD void stw(uint32_t* base, uint32_t o, size_t word_off, uint32_t v, int mem = MEM_STREAM) {
     const __amdgpu_buffer_rsrc_t r = te_rsrc(base);
     if (mem == MEM_AGENT) __builtin_amdgcn_raw_buffer_store_b32(v, r, (int)o, (int)(uint32_t)(word_off * 4u), TE_AUX_SC1);
+    else if (mem == MEM_AFFINE) __builtin_amdgcn_raw_buffer_store_b32(v, r, (int)o, (int)(uint32_t)(word_off * 4u), 0);
     else __builtin_amdgcn_raw_buffer_store_b32(v, r, (int)o, (int)(uint32_t)(word_off * 4u), TE_ST_NT ? TE_AUX_NT : 0);
 }
 #else
 TE_HD uint32_t ldw(const uint32_t* base, uint32_t o, size_t word_off, int mem = MEM_STREAM) {
     const uint32_t* p = (const uint32_t*)((const char*)(base + word_off) + o);
-    return mem == MEM_AGENT ? ld_agent(p) : ld_stream(p);
+    return mem != MEM_STREAM ? ld_agent(p) : ld_stream(p);
 }
 TE_HD void stw(uint32_t* base, uint32_t o, size_t word_off, uint32_t v, int mem = MEM_STREAM) {
     uint32_t* p = (uint32_t*)((char*)(base + word_off) + o);
-    if (mem == MEM_AGENT) st_agent(p, v); else st_stream(p, v);
+    if (mem != MEM_STREAM) st_agent(p, v); else st_stream(p, v);
 }
 #endif
 #if defined(__HIP_DEVICE_COMPILE__)

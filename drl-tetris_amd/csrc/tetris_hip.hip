@@ -50,8 +50,21 @@ constexpr int CHAIN_STREAMS = TE_CHAIN_STREAMS;
 template <int P>
 __global__ __launch_bounds__(64) void k_chain(KArgs a) {
     __shared__ __attribute__((aligned(16))) uint32_t s_shapes[SHAPE_WORDS];
-    const int lane = threadIdx.x, wave = blockIdx.x;
+    const int lane = threadIdx.x;
     if (a.steps < 0) { chain_census(a, lane == 0); return; }
+#if defined(TE_EXPERIMENT_AFFINE)
+    // experiment (profiles/r03/handoff_experiments.txt): the games of a block follow the workgroup's XCD — block (b & ~7) | XCC_ID — so
+    // that a game is stepped on the same XCD in every launch and its state can stay in that XCD's L2 (plain stores).  Blocks are
+    // dealt round-robin over the XCDs from a start that differs per stream, so the map is a bijection; NOTHING here verifies that.
+    // Bit-exact in a 2000-launch soak and 0.1 us per launch SLOWER than the write-through hand-off: not the product path.
+    uint32_t xcc_;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_));
+    const int wave = (int)((blockIdx.x & ~7u) | (xcc_ & 7u));
+    constexpr int CMEM = MEM_AFFINE;
+#else
+    const int wave = blockIdx.x;
+    constexpr int CMEM = MEM_AGENT;
+#endif
     const int i = wave * CHAIN_LANES + lane;
     const bool active = lane < CHAIN_LANES && i < a.n;
     LaneCounters cnt = {0, 0, 0, 0};
@@ -66,20 +79,24 @@ __global__ __launch_bounds__(64) void k_chain(KArgs a) {
     TE_STAMP_CHAIN(a.epoch, 1);
     if (!chain_wait(a, (uint32_t)wave, lane == 0)) return;      // gave up: the games stay as launch E - 1 (or an earlier one) left them
     TE_STAMP_CHAIN(a.epoch, 2);
-    if (active) { load_game<P>(geo_of(a), (size_t)i, g, false, P > 1, true, MEM_AGENT, CHAIN_LANES == 64); g.draw0 = d0; g.draw1 = d1; }
+    if (active) { load_game<P>(geo_of(a), (size_t)i, g, false, P > 1, true, CMEM, CHAIN_LANES == 64); g.draw0 = d0; g.draw1 = d1; }
 #if defined(TE_PHASE_TRACE)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // diagnostic: when have ALL state words arrived
     TE_STAMP_CHAIN(a.epoch, 3);
 #endif
     s_shapes[lane] = shape_word;
     __builtin_amdgcn_wave_barrier();
-    if (active) game_run<P, M_ROLLOUT, false, MEM_AGENT>(a, i, s_shapes, g, cnt);
+    if (active) game_run<P, M_ROLLOUT, false, CMEM>(a, i, s_shapes, g, cnt);
     TE_STAMP_CHAIN(a.epoch, 4);
 #if !defined(TE_EXPERIMENT_NO_ACK)      // (timing experiment only, results INVALID: what would a hand-off that does not wait for the store acknowledgements gain?)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every store (and counter atomic) of this wave has been acknowledged
 #endif
     TE_STAMP_CHAIN(a.epoch, 5);
+#if defined(TE_EXPERIMENT_AFFINE)
+    if (lane == 0) *(volatile uint32_t*)(a.chain + (size_t)wave * CHAIN_STRIDE) = a.epoch;
+#else
     if (lane == 0) st_agent(a.chain + (size_t)wave * CHAIN_STRIDE, a.epoch);
+#endif
     TE_STAMP_CHAIN(a.epoch, 6);
 }
 

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""argv: [launches [players]].  Soak of the chained rollout launches: 65 536 boards x N single-step launches (default 10 000 = 6.6e8 env-steps,
+"""argv: [launches [players [library build]]].  Soak of the chained rollout launches: 65 536 boards x N single-step launches (default 10 000 = 6.6e8 env-steps,
 ~3e7 episodes) on the rotating chain streams with per-wave epoch hand-over, then counters and EVERY board's complete state against
 the oracle on all host cores.  A stale read anywhere in the hand-over would show up here as a diverging board."""
 import os
@@ -17,7 +17,8 @@ steps = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
 P = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 n = 65536
 seeds = orc.episode_seed(np.arange(n), 0)
-eng = ge.package().TetrisBatch(n, P, 20, 10, seeds=seeds, device=0)
+lib = os.path.abspath(sys.argv[3]) if len(sys.argv) > 3 else None
+eng = ge.package().TetrisBatch(n, P, 20, 10, seeds=seeds, device=0, lib_path=lib)
 ref = orc.OracleBatch(n, P, 20, 10, seeds=seeds)
 assert eng.rollout_is_chained(1)
 t0 = time.time()
