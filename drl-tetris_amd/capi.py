@@ -57,6 +57,8 @@ _SIGNATURES = {
     "tetris_set_game_offset": (C.c_int, [C.c_void_p, C.c_uint64]),
     "tetris_set_chained": (C.c_int, [C.c_void_p, C.c_int]),
     "tetris_rollout_is_chained": (C.c_int, [C.c_void_p, C.c_int]),
+    "tetris_set_direct_dispatch": (C.c_int, [C.c_void_p, C.c_int]),
+    "tetris_rollout_was_direct": (C.c_int, [C.c_void_p]),
     "tetris_set_chain_spin_limit": (C.c_int, [C.c_void_p, C.c_uint32]),
     "tetris_debug_stall": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "tetris_debug_clock_khz": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -377,6 +379,17 @@ class TetrisBatch:
     def set_chained(self, on):
         """Chained launches of the built-in rollout on / off (include/tetris_hip.h: tetris_set_chained)."""
         self._check(self.lib.tetris_set_chained(self._h, 1 if on else 0))
+
+    def set_direct_dispatch(self, on):
+        """Chained launches through HSA queues of the batch's own (AQL packets written by the library) on / off
+        (include/tetris_hip.h: tetris_set_direct_dispatch)."""
+        self._check(self.lib.tetris_set_direct_dispatch(self._h, 1 if on else 0))
+
+    def rollout_was_direct(self):
+        rc = self.lib.tetris_rollout_was_direct(self._h)
+        if rc < 0:
+            self._check(rc)
+        return bool(rc)
 
     def set_chain_spin_limit(self, polls):
         """Polls of the predecessor's epoch word after which a waiting wave of a chained launch gives up (0 = default, ~2 s)."""

@@ -793,6 +793,8 @@ struct Stage {
 #ifndef TE_GATE_GROUP
 #define TE_GATE_GROUP 120
 #endif
+#include "tetris_aql.h"
+
 struct tetris_batch {
     int device = 0, N = 0, P = 0, H = 0;
     int stride = 0;                      // games per row of the state arrays: N + padding (see create_impl)
@@ -828,6 +830,11 @@ struct tetris_batch {
     bool chain_fell_back = false;        // a chained call was finished un-chained since the last tetris_take_errors (TETRIS_ERR_CHAIN_FELL_BACK)
     uint32_t* h_chain = nullptr;         // host copy of the epoch words (chain_recover)
     hipStream_t stall_stream = nullptr;  // tetris_debug_stall(.., -1, ..)
+    // direct dispatch of the chained launches (tetris_aql.h): queues of the batch's own; off when anything about it failed
+    aql::Queues aq;
+    int use_direct = 1;                  // TETRIS_DIRECT=0 in the environment / tetris_set_direct_dispatch
+    bool last_direct = false;            // the last rollout call went through the batch's own queues
+    bool stream_stalled = false;         // tetris_debug_stall held a chain STREAM: the next rollout call takes the stream path
     bool home_async = false;             // asynchronous (_dev) work was enqueued on the batch's stream since the last drain
     bool busy = true;                    // something was enqueued on one of the batch's streams since the last drain
     // Run-ahead gate of the asynchronous entry points: every GATE_GROUP launches an event is recorded; before a new group is
@@ -1117,6 +1124,8 @@ int tetris_destroy(tetris_batch* b) {
     (void)hipFree(b->d_chain);
     free(b->h_chain);
     if (b->stall_stream) { (void)hipStreamSynchronize(b->stall_stream); (void)hipStreamDestroy(b->stall_stream); }
+    aql::quiesce(b->aq);
+    aql::destroy_queues(b->aq);
     Stage* all[] = {&b->s_idx, &b->s_in0, &b->s_in1, &b->s_in2, &b->s_out0, &b->s_out1, &b->s_out2, &b->s_big, &b->s_act0, &b->s_act1, &b->s_act2};
     for (Stage* s : all) s->release();
     if (b->ev0) (void)hipEventDestroy(b->ev0);
@@ -1154,6 +1163,7 @@ static int create_impl(tetris_batch** out, int n_games, int n_players, int heigh
     b->tint = (flags & TETRIS_FLAG_COLOURS) ? 1 : 0;
     { const char* e = getenv("TETRIS_NO_DUO"); b->use_duo = !(e && e[0] == '1'); }
     { const char* e = getenv("TETRIS_NO_CHAIN"); b->use_chain = !(e && e[0] == '1'); }
+    { const char* e = getenv("TETRIS_DIRECT"); b->use_direct = !(e && e[0] == '0'); }
     { const char* e = getenv("TETRIS_GRAPH"); b->use_graph = (e && e[0] == '1'); }
     { const char* e = getenv("TETRIS_CHAIN_SPIN_LIMIT"); if (e && atoll(e) > 0) b->chain_spin_limit = (uint32_t)atoll(e); }
     b->nw = b->tint ? NWORDS_TINT : NWORDS;
@@ -1229,6 +1239,20 @@ int tetris_set_chained(tetris_batch* b, int on) {
     return TETRIS_OK;
 }
 
+int tetris_set_direct_dispatch(tetris_batch* b, int on) {
+    int rc = check_batch(b);
+    if (rc) return rc;
+    if ((rc = finish_call(b))) return rc;
+    b->use_direct = on ? 1 : 0;
+    return TETRIS_OK;
+}
+
+int tetris_rollout_was_direct(tetris_batch* b) {
+    int rc = check_batch(b, false);
+    if (rc) return rc;
+    return b->last_direct ? 1 : 0;
+}
+
 int tetris_set_chain_spin_limit(tetris_batch* b, uint32_t polls) {
     int rc = check_batch(b, false);
     if (rc) return rc;
@@ -1245,9 +1269,19 @@ int tetris_debug_stall(tetris_batch* b, int which, int microseconds, int percent
     if (rc) return rc;
     if (which < -1 || which > 3 || microseconds < 0 || microseconds > 2000000 || percent < 0 || percent > 100) return fail(TETRIS_E_ARG, "which / microseconds / percent");
     const unsigned long long ticks = (unsigned long long)microseconds * 100ull;
+    if (which >= 0 && which < 3 && b->use_direct && b->aq.ok && which < b->chain_depth) {
+        // the batch launches through queues of its own (tetris_aql.h): the idle kernel goes to the one that stands for that stream
+        aql::Device* dev = aql::device_for(b->device);
+        if (!dev->ok || !dev->blocker.ok) return fail(TETRIS_E_HIP, "direct dispatch: no idle kernel in the loaded code object");
+        struct { const uint32_t* go; unsigned long long ticks; } args = {nullptr, ticks};
+        aql::Pending pd;
+        aql::write_dispatch(b->aq, pd, which, dev->blocker, &args, sizeof args, 1, HSA_FENCE_SCOPE_AGENT, HSA_FENCE_SCOPE_AGENT, hsa_signal_t{});
+        aql::ring(b->aq, pd);
+        return TETRIS_OK;
+    }
     if (which >= 0) {
         hipStream_t st = which == 3 ? b->stream : b->chain_stream[which % CHAIN_STREAMS];
-        if (which < 3) b->chain_pending = true;
+        if (which < 3) { b->chain_pending = true; b->stream_stalled = true; }
         hipLaunchKernelGGL(k_blocker, dim3(1), dim3(64), 0, st, (const uint32_t*)nullptr, ticks);
     } else {
         if (!b->stall_stream) HIP_TRY(hipStreamCreateWithFlags(&b->stall_stream, hipStreamNonBlocking));
@@ -1975,6 +2009,96 @@ static int chain_recover(tetris_batch* b) {
     return TETRIS_OK;
 }
 
+// The launches of one chained call through the batch's own queues (tetris_aql.h).  Returns with every packet retired.
+// `group`: run-ahead of the whole call in launches (as for gate_launch); b->chain_epoch has not been advanced yet.
+static int rollout_direct(tetris_batch* b, aql::Device* dev, int launches, int steps_per_launch, uint32_t policy_seed, uint64_t first_step,
+                          int ms, int group, float* elapsed_ms) {
+    aql::Queues& qs = b->aq;
+    const int depth = b->chain_depth;
+    const aql::Kernel& kern = b->P == 1 ? dev->chain1 : dev->duo;
+    const uint32_t blocks = b->P == 1 ? (uint32_t)((b->N + CHAIN_LANES - 1) / CHAIN_LANES) : (uint32_t)((b->N + 31) / 32);
+    const int wgroup = std::min(aql::SLOTS / 2 - 2, std::max(8, group / depth));
+    static const bool timing = getenv("TETRIS_TIMING") != nullptr;
+    // (experiment knob: the packets between a queue's first and last with fence scope "none" instead of "agent")
+    static const int mid_scope = [] { const char* e = getenv("TETRIS_DIRECT_FENCE"); return e && !strcmp(e, "none") ? HSA_FENCE_SCOPE_NONE : HSA_FENCE_SCOPE_AGENT; }();
+    const auto t_begin = std::chrono::steady_clock::now();
+    uint64_t h_begin = 0, h_seen = 0;
+    if (timing) (void)hsa_system_get_info(HSA_SYSTEM_INFO_TIMESTAMP, &h_begin);
+    const uint32_t epoch0 = b->chain_epoch;
+    b->chain_epoch = epoch0 + (uint32_t)launches;       // (a launch that never gets enqueued leaves waves waiting: they give up, chain_recover finishes the call)
+    aql::Pending pd;
+    bool gate_pending[CHAIN_STREAMS][2] = {}, done_armed[CHAIN_STREAMS] = {};
+    int mine[CHAIN_STREAMS] = {}, gate_slot[CHAIN_STREAMS] = {};
+    // whatever happens below, every packet that was written is rung in and retired before this function returns
+    auto drain = [&]() {
+        aql::ring(qs, pd);
+        bool ok = true;
+        for (int k = 0; k < depth; k++) {
+            if (!pd.wrote[k]) continue;
+            if (!done_armed[k]) {          // the call ended early: a barrier packet behind what queue k holds carries its completion signal
+                hsa_signal_store_relaxed(qs.done[k], 1);
+                aql::write_barrier(qs, pd, k, qs.done[k]);
+                done_armed[k] = true;
+                aql::ring(qs, pd);
+            }
+            ok = aql::wait_signal(qs.done[k]) && ok;
+        }
+        return ok;
+    };
+    struct DrainGuard { decltype(drain)& d; bool armed; ~DrainGuard() { if (armed) (void)d(); } } guard{drain, true};
+    hsa_signal_t start_sig = qs.first, end_sig = qs.done[(launches - 1) % depth];
+    int rc = TETRIS_OK, unflushed = 0;
+    for (int l = 0; l < launches; l++) {
+        const int k = l % depth;
+        if ((rc = service_flags(b))) return rc;
+        hsa_signal_t sig{};
+        const bool first_on_queue = l < depth, last_on_queue = l >= launches - depth;
+        if (last_on_queue) { hsa_signal_store_relaxed(qs.done[k], 1); sig = qs.done[k]; done_armed[k] = true; if (l == 0) start_sig = sig; }
+        else if (l == 0) { hsa_signal_store_relaxed(qs.first, 1); sig = qs.first; }
+        else if (mine[k] >= wgroup) {                    // at most 2 * wgroup + 1 packets of this queue outstanding
+            const int sl = gate_slot[k];
+            if (gate_pending[k][sl]) { aql::ring(qs, pd); if (!aql::wait_signal(qs.gate[k][sl])) return fail(TETRIS_E_HIP, "direct dispatch: a flow-control signal never came"); }
+            hsa_signal_store_relaxed(qs.gate[k][sl], 1);
+            sig = qs.gate[k][sl]; gate_pending[k][sl] = true; gate_slot[k] = sl ^ 1; mine[k] = 0;
+        }
+        mine[k]++;
+        KArgs a = base_args(b, b->N, nullptr);
+        a.ms = ms; a.steps = steps_per_launch; a.policy_seed = policy_seed;
+        a.first_step = first_step + (uint64_t)l * (uint64_t)steps_per_launch;
+        a.chain = b->d_chain; a.epoch = epoch0 + (uint32_t)l + 1u; a.chain_spin_limit = b->chain_spin_limit;
+        static const int edge_scope = [] { const char* e = getenv("TETRIS_DIRECT_EDGE"); return e && !strcmp(e, "agent") ? HSA_FENCE_SCOPE_AGENT : HSA_FENCE_SCOPE_SYSTEM; }();   // (experiment knob)
+        aql::write_dispatch(qs, pd, k, kern, &a, sizeof a, blocks, first_on_queue ? edge_scope : mid_scope, last_on_queue ? edge_scope : mid_scope, sig);
+        // the first launches go out one by one (the GPU is idle), later ones eight at a time (one fence + read back per eight)
+        if (++unflushed >= 8 || l < 2 * depth || l == launches - 1) { aql::ring(qs, pd); unflushed = 0; }
+    }
+    b->chain_pending = true;
+    const auto t_enq = std::chrono::steady_clock::now();
+    guard.armed = false;
+    if (!drain()) return fail(TETRIS_E_HIP, "direct dispatch: a completion signal never came");
+    b->chain_pending = false;
+    const auto t_seen = std::chrono::steady_clock::now();
+    const double seen_us = std::chrono::duration<double>(t_seen - t_begin).count() * 1e6;
+    if (timing) (void)hsa_system_get_info(HSA_SYSTEM_INFO_TIMESTAMP, &h_seen);
+    float ms_events = 0.0f;
+    hsa_amd_profiling_dispatch_time_t t0{}, t1{};
+    {
+        if (hsa_amd_profiling_get_dispatch_time(dev->gpu, start_sig, &t0) == HSA_STATUS_SUCCESS &&
+            hsa_amd_profiling_get_dispatch_time(dev->gpu, end_sig, &t1) == HSA_STATUS_SUCCESS && t1.end >= t0.start)
+            ms_events = (float)((double)(t1.end - t0.start) * 1e3 / (double)dev->ts_freq);
+    }
+    if ((rc = finish_call(b, true))) return rc;
+    if (elapsed_ms) *elapsed_ms = ms_events;
+    if (timing) {
+        const double enq = std::chrono::duration<double>(t_enq - t_begin).count();
+        const double tick_us = 1e6 / (double)dev->ts_freq;
+        fprintf(stderr, "[tetris timing] %d launches, direct dispatch: host enqueue %.2f us/launch, last signal seen %.1f us after the first enqueue, between first start and last end %.1f us; "
+                "first enqueue -> first start %.1f us, last end -> seen %.1f us, after that %.1f us\n",
+                launches, enq * 1e6 / launches, seen_us, ms_events * 1e3, (double)(int64_t)(t0.start - h_begin) * tick_us, (double)(int64_t)(h_seen - t1.end) * tick_us,
+                std::chrono::duration<double>(std::chrono::steady_clock::now() - t_seen).count() * 1e6);
+    }
+    return TETRIS_OK;
+}
+
 int tetris_rollout_launch(tetris_batch* b, int launches, int steps_per_launch, uint32_t policy_seed, uint64_t first_step,
                           int ms, float* elapsed_ms) {
     const auto t_entry = std::chrono::steady_clock::now();
@@ -2075,6 +2199,21 @@ int tetris_rollout_launch(tetris_batch* b, int launches, int steps_per_launch, u
         for (int k = 0; k < CHAIN_STREAMS; k++) HIP_TRY(hipStreamWaitEvent(b->chain_stream[k], b->chain_ev[CHAIN_STREAMS], 0));
         group = 1 << 20;
     }
+    b->last_direct = false;
+    if (chained && !prequeue && b->use_direct && !b->stream_stalled) {
+        // the batch's own queues (tetris_aql.h); anything that keeps them from being set up switches them off for this batch
+        aql::Device* dev = aql::device_for(b->device);
+        std::string why = dev->why;
+        if (dev->ok && aql::make_queues(dev, b->aq, b->chain_depth, why)) {
+            if (b->home_async) { HIP_TRY(hipStreamSynchronize(home)); }      // what the batch's stream still holds comes first
+            b->last_direct = true;
+            if (getenv("TETRIS_TIMING")) fprintf(stderr, "[tetris timing] call entry -> direct dispatch %.1f us\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_entry).count() * 1e6);
+            return rollout_direct(b, dev, launches, steps_per_launch, policy_seed, first_step, ms, group, elapsed_ms);
+        }
+        b->use_direct = 0;
+        if (getenv("TETRIS_TIMING")) fprintf(stderr, "[tetris] direct dispatch is off: %s\n", why.c_str());
+    }
+    b->stream_stalled = false;
     struct GoGuard {                              // (no return path leaves the blocker waiting for its flag)
         tetris_batch* b; bool armed;
         ~GoGuard() { if (armed) ((volatile uint32_t*)b->flags)[F_GO] = 1; }

@@ -23,7 +23,7 @@ ref = orc.OracleBatch(n, P, 20, 10, seeds=seeds)
 assert eng.rollout_is_chained(1)
 t0 = time.time()
 c, ms = eng.rollout_random(steps, 1)
-print(f"gpu: {steps} chained launches, {ms * 1e3 / steps:.2f} us per launch", flush=True)
+print(f"gpu: {steps} chained launches, {ms * 1e3 / steps:.2f} us per launch (direct dispatch: {eng.rollout_was_direct()})", flush=True)
 _, want = ref.rollout_random(steps, threads=min(32, len(os.sched_getaffinity(0))))
 print(f"oracle done after {time.time() - t0:.0f} s", flush=True)
 assert c.tolist() == want.tolist(), (c.tolist(), want.tolist())
