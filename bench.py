@@ -296,6 +296,7 @@ def main():
         shard.run(args.warmup, S)                     # untimed warm-up
     res = shard.run(args.steps, S)                    # exactly K timed launches
     counters, wall, ev_ms = res["counters"], res["wall_s"], res["event_ms"]
+    direct = bool(shard.batch.rollout_was_direct())       # (asked now: the GPU-paced extra run below goes through the streams)
     batch = shard
     # after the timed region, single GPU, chained single-step launches only: the same launches GPU-paced (the library parks its
     # streams behind a blocker kernel until all 512 launches are queued) — the period the GPU sustains when the host's launch
@@ -328,10 +329,13 @@ def main():
         lib_path = os.path.abspath(os.environ.get("BENCH_LIB_PATH") or ge.LIB)
         roofline = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "kernel": (("k_chain<1>" if P == 1 else "k_duo<M_ROLLOUT, true>") + " (chained launches: consecutive launches on "
-                               + ("three" if P == 1 else "two") + " streams, each wave waits for its own predecessor's epoch word)") if chained
+                               + ("three" if P == 1 else "two") + " queues / streams, each wave waits for its own predecessor's epoch word)") if chained
                               else ("k_duo<M_ROLLOUT>" if (P == 2 and S == 1) else f"k_game<{P}, M_ROLLOUT>"),
                     "launch_us": launch_us, "launch_us_events": launch_us_events, "clock": "wall (same clock as `value`)"}
         if chained:
+            roofline["dispatch"] = ("direct: the K launches are AQL packets the library writes into HSA queues of the batch's own (include/tetris_hip.h: "
+                                    "tetris_set_direct_dispatch); `launch_us_events` = (end of the last dispatch - start of the first) / K from the packets' own timestamps"
+                                    if direct else "streams: hipLaunchKernel on the batch's chain streams; `launch_us_events` from HIP events attached to the first and last kernel")
             roofline["launch_us_is"] = ("the launch PERIOD: consecutive launches overlap (a wave of launch E starts as soon as the same wave of "
                                         "launch E-1 has published its state), so the durations in a kernel trace are longer than the period "
                                         "(profiles/r03/final/chain_period_from_trace_p*.json derives the period from the trace's own timestamps); "

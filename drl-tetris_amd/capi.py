@@ -380,10 +380,11 @@ class TetrisBatch:
         """Chained launches of the built-in rollout on / off (include/tetris_hip.h: tetris_set_chained)."""
         self._check(self.lib.tetris_set_chained(self._h, 1 if on else 0))
 
-    def set_direct_dispatch(self, on):
-        """Chained launches through HSA queues of the batch's own (AQL packets written by the library) on / off
-        (include/tetris_hip.h: tetris_set_direct_dispatch)."""
-        self._check(self.lib.tetris_set_direct_dispatch(self._h, 1 if on else 0))
+    def set_direct_dispatch(self, on, min_launches=None):
+        """Long chained calls through HSA queues of the library's own (AQL packets written by the library) on / off;
+        min_launches: calls of at least that many launches (default: the library's, 128) — include/tetris_hip.h:
+        tetris_set_direct_dispatch."""
+        self._check(self.lib.tetris_set_direct_dispatch(self._h, 0 if not on else (-1 if min_launches is None else max(1, int(min_launches)))))
 
     def rollout_was_direct(self):
         rc = self.lib.tetris_rollout_was_direct(self._h)

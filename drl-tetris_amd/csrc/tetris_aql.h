@@ -14,22 +14,39 @@
 //    them before the doorbell rings.
 //  * the hidden arguments of code object v5 behind the explicit ones (block counts, group sizes, grid dims).
 //  * ordering: every packet has the barrier bit (a queue's launches run one after the other, as on a stream — chain_fits counts on
-//    at most `depth` launches in flight); the first packet of a queue acquires and the last releases at system scope, the ones in
-//    between at agent scope.
+//    at most `depth` launches in flight); the first packet of a queue acquires at system scope, everything else is agent scope
+//    (rollout_direct in tetris_hip.hip says why that is enough for these kernels).
 //  * flow control: every `wgroup`-th packet of a queue carries a completion signal; at most 2 * wgroup + 1 packets per queue are
 //    outstanding (the margin of the RNG tables is sized for that, as for the stream path's gate).
-// Anything that fails while setting this up switches it off for the process (the stream path remains); TETRIS_DIRECT=0 in the
+// The queues belong to the DEVICE, not to a batch (chained calls of a device's batches exclude each other anyway): three more
+// hardware queues per process and GPU, however many batches there are.
+// Only calls of at least `direct_min` launches (default 128) go this way.  A queue that has been idle for ~100 us takes 10 us from
+// doorbell to first wave instead of 5 (profiles/r03/aql_probe.txt), as a stream's does, and in calls as short as the driver's 20
+// launches the stream path — whose first launches the runtime has to prepare anyway while the queue wakes — came out 5-12 us
+// ahead (profiles/r03/direct_dispatch.txt); from a few hundred launches on the queues are 1.5-2 % faster and need no helper threads.
+// Anything that fails while setting this up switches it off for the batch (the stream path remains); TETRIS_DIRECT=0 in the
 // environment or tetris_set_direct_dispatch(b, 0) do the same by hand.
 #pragma once
 #include <hsa/hsa.h>
 #include <hsa/hsa_ext_amd.h>
 #include <dlfcn.h>
+#include <atomic>
 #include <immintrin.h>
 
 namespace aql {
 
 struct Kernel { uint64_t object = 0; uint32_t kernarg = 0, group = 0, priv = 0; bool ok = false; };
 
+struct Queues {                        // one set per device: chained calls of a device's batches exclude each other (chain_acquire)
+    hsa_queue_t* q[CHAIN_STREAMS] = {};
+    char* kernarg[CHAIN_STREAMS] = {};           // [SLOTS][slot_bytes] each, device memory, host-visible
+    uint32_t slot_bytes = 0;
+    std::atomic<uint64_t> issued[CHAIN_STREAMS]; // packets ever written to queue k (kernarg slot = issued % SLOTS)
+    hsa_signal_t gate[CHAIN_STREAMS][2] = {};    // flow control
+    hsa_signal_t done[CHAIN_STREAMS] = {};       // last packet of a call on queue k
+    hsa_signal_t first{};                        // first packet of a call (its start time)
+    bool ok = false;
+};
 struct Device {                        // one per HIP device of the process, made on first use, never torn down
     int hip_device = -1;
     bool tried = false, ok = false;
@@ -38,19 +55,11 @@ struct Device {                        // one per HIP device of the process, mad
     uint64_t ts_freq = 0;
     std::vector<hsa_executable_t> exes;
     Kernel chain1, duo, blocker;
+    std::vector<std::vector<char>> images;   // the code objects' bytes: the loader (and a profiler's code-object tracking) keep reading them
+    Queues qs;
     std::string why;                   // why it is not ok
 };
 
-struct Queues {                        // one set per batch
-    hsa_queue_t* q[CHAIN_STREAMS] = {};
-    char* kernarg[CHAIN_STREAMS] = {};           // [SLOTS][slot_bytes] each, device memory, host-visible
-    uint32_t slot_bytes = 0;
-    uint64_t issued[CHAIN_STREAMS] = {};         // packets ever written to queue k (kernarg slot = issued % SLOTS)
-    hsa_signal_t gate[CHAIN_STREAMS][2] = {};    // flow control
-    hsa_signal_t done[CHAIN_STREAMS] = {};       // last packet of a call on queue k
-    hsa_signal_t first{};                        // first packet of a call (its start time)
-    bool ok = false;
-};
 constexpr int SLOTS = 512;             // kernel-argument slots per queue (> 2 * wgroup + 1)
 constexpr uint32_t QUEUE_PACKETS = 1024;
 
@@ -157,6 +166,14 @@ static Device* device_for(int hip_device) {
     d->tried = true;
     g_devices.push_back(d);
     auto bad = [&](const std::string& w) { d->why = w; d->ok = false; return d; };
+    {   // A profiler that intercepts HSA queues (rocprofv3 preloads its tool library) stands between a doorbell and the hardware: every
+        // packet is copied and rewritten on the way.  One-player runs were traced correctly that way, the two-player bench crashed inside
+        // the tool (profiles/r03/direct_dispatch.txt) — with a tool library in the process the launches stay on the streams.
+        const char* tools[] = {getenv("ROCP_TOOL_LIBRARIES"), getenv("HSA_TOOLS_LIB"), getenv("LD_PRELOAD")};
+        for (const char* t : tools)
+            if (t && (strstr(t, "rocprofiler") || strstr(t, "roctracer") || strstr(t, "rocprof")) && !getenv("TETRIS_DIRECT_UNDER_TOOLS"))
+                return bad("a profiling tool intercepts the HSA queues");
+    }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, hip_device) != hipSuccess) return bad("hipGetDeviceProperties failed");
     if (hsa_init() != HSA_STATUS_SUCCESS) return bad("hsa_init failed");
@@ -167,10 +184,9 @@ static Device* device_for(int hip_device) {
     if (d->dev_pool.handle == 0) return bad("no coarse-grained device memory pool");
     (void)hsa_system_get_info(HSA_SYSTEM_INFO_TIMESTAMP_FREQUENCY, &d->ts_freq);
     if (!d->ts_freq) return bad("no timestamp frequency");
-    std::vector<std::vector<char>> images;
     std::string why;
-    if (!own_code_objects(images, why)) return bad(why);
-    for (auto& img : images) {
+    if (!own_code_objects(d->images, why)) return bad(why);
+    for (auto& img : d->images) {
         hsa_code_object_reader_t reader;
         hsa_executable_t exe;
         if (hsa_code_object_reader_create_from_memory(img.data(), img.size(), &reader) != HSA_STATUS_SUCCESS) continue;
@@ -198,15 +214,25 @@ static void destroy_queues(Queues& qs) {
         if (qs.done[k].handle) (void)hsa_signal_destroy(qs.done[k]);
     }
     if (qs.first.handle) (void)hsa_signal_destroy(qs.first);
-    qs = Queues();
+    for (int k = 0; k < CHAIN_STREAMS; k++) { qs.q[k] = nullptr; qs.kernarg[k] = nullptr; qs.done[k] = hsa_signal_t{}; qs.gate[k][0] = qs.gate[k][1] = hsa_signal_t{}; }
+    qs.first = hsa_signal_t{}; qs.ok = false;
 }
 
-static bool make_queues(Device* d, Queues& qs, int depth, std::string& why) {
+static bool make_queues(Device* d, std::string& why) {
+    std::lock_guard<std::mutex> lock(g_mutex);
+    Queues& qs = d->qs;
+    const int depth = CHAIN_STREAMS;
     if (qs.ok) return true;
+    for (int k = 0; k < CHAIN_STREAMS; k++) qs.issued[k].store(0);
     qs.slot_bytes = ((std::max(d->chain1.kernarg, d->duo.kernarg) + 63u) & ~63u) + 64u;
     for (int k = 0; k < depth; k++) {
         if (hsa_queue_create(d->gpu, QUEUE_PACKETS, HSA_QUEUE_TYPE_MULTI, nullptr, nullptr, UINT32_MAX, UINT32_MAX, &qs.q[k]) != HSA_STATUS_SUCCESS) { why = "hsa_queue_create failed"; destroy_queues(qs); return false; }
         (void)hsa_amd_profiling_set_profiler_enabled(qs.q[k], 1);
+        {   // (experiment knob TETRIS_DIRECT_PRIO=high: no effect that survives swapping the order in which the batches of a process
+            // are created — profiles/r03/direct_dispatch.txt)
+            const char* e = getenv("TETRIS_DIRECT_PRIO");
+            if (e && !strcmp(e, "high")) (void)hsa_amd_queue_set_priority(qs.q[k], HSA_AMD_QUEUE_PRIORITY_HIGH);
+        }
         if (hsa_amd_memory_pool_allocate(d->dev_pool, (size_t)SLOTS * qs.slot_bytes + 4096, 0, (void**)&qs.kernarg[k]) != HSA_STATUS_SUCCESS ||
             hsa_amd_agents_allow_access(1, &d->cpu, nullptr, qs.kernarg[k]) != HSA_STATUS_SUCCESS) { why = "no host-visible device memory for the kernel arguments"; destroy_queues(qs); return false; }
         for (int s = 0; s < 2; s++)
@@ -266,7 +292,7 @@ static inline char* claim_packet(Queues& qs, Pending& pd, int k) {
 // one kernel launch of `blocks` workgroups of 64 lanes on queue k: arguments into the queue's next slot, then the packet (its header last)
 static inline void write_dispatch(Queues& qs, Pending& pd, int k, const Kernel& kern, const void* args, size_t arg_bytes, uint32_t blocks,
                                   int acquire, int release, hsa_signal_t signal) {
-    char* slot = qs.kernarg[k] + (size_t)(qs.issued[k]++ % SLOTS) * qs.slot_bytes;
+    char* slot = qs.kernarg[k] + (size_t)(qs.issued[k].fetch_add(1) % SLOTS) * qs.slot_bytes;
     memcpy(slot, args, arg_bytes);
     fill_hidden(slot, (uint32_t)((arg_bytes + 7) & ~(size_t)7), qs.slot_bytes, blocks, 64);
     pd.last_slot = slot;

@@ -659,6 +659,7 @@ struct tetris_batch;
 static void chain_release(tetris_batch* b);
 static int chain_recover(tetris_batch* b);
 static thread_local std::string g_err;
+static int default_direct_min();
 static int fail(int code, const std::string& msg) {
     g_err = msg;
     return code;
@@ -831,10 +832,9 @@ struct tetris_batch {
     uint32_t* h_chain = nullptr;         // host copy of the epoch words (chain_recover)
     hipStream_t stall_stream = nullptr;  // tetris_debug_stall(.., -1, ..)
     // direct dispatch of the chained launches (tetris_aql.h): queues of the batch's own; off when anything about it failed
-    aql::Queues aq;
-    int use_direct = 1;                  // TETRIS_DIRECT=0 in the environment / tetris_set_direct_dispatch
-    bool last_direct = false;            // the last rollout call went through the batch's own queues
-    bool stream_stalled = false;         // tetris_debug_stall held a chain STREAM: the next rollout call takes the stream path
+    int direct_min = 128;                // calls of at least this many launches go through the device's own queues; 0: never (TETRIS_DIRECT=0 / TETRIS_DIRECT_MIN, tetris_set_direct_dispatch)
+    bool last_direct = false;            // the last rollout call went through those queues
+    bool direct_used = false;            // ... and so did some call of this batch (its destruction waits for the queues)
     bool home_async = false;             // asynchronous (_dev) work was enqueued on the batch's stream since the last drain
     bool busy = true;                    // something was enqueued on one of the batch's streams since the last drain
     // Run-ahead gate of the asynchronous entry points: every GATE_GROUP launches an event is recorded; before a new group is
@@ -1124,8 +1124,7 @@ int tetris_destroy(tetris_batch* b) {
     (void)hipFree(b->d_chain);
     free(b->h_chain);
     if (b->stall_stream) { (void)hipStreamSynchronize(b->stall_stream); (void)hipStreamDestroy(b->stall_stream); }
-    aql::quiesce(b->aq);
-    aql::destroy_queues(b->aq);
+    if (b->direct_used) { aql::Device* dev = aql::device_for(b->device); if (dev->ok) aql::quiesce(dev->qs); }      // (a test's idle kernel may still sit there)
     Stage* all[] = {&b->s_idx, &b->s_in0, &b->s_in1, &b->s_in2, &b->s_out0, &b->s_out1, &b->s_out2, &b->s_big, &b->s_act0, &b->s_act1, &b->s_act2};
     for (Stage* s : all) s->release();
     if (b->ev0) (void)hipEventDestroy(b->ev0);
@@ -1163,7 +1162,7 @@ static int create_impl(tetris_batch** out, int n_games, int n_players, int heigh
     b->tint = (flags & TETRIS_FLAG_COLOURS) ? 1 : 0;
     { const char* e = getenv("TETRIS_NO_DUO"); b->use_duo = !(e && e[0] == '1'); }
     { const char* e = getenv("TETRIS_NO_CHAIN"); b->use_chain = !(e && e[0] == '1'); }
-    { const char* e = getenv("TETRIS_DIRECT"); b->use_direct = !(e && e[0] == '0'); }
+    b->direct_min = default_direct_min();
     { const char* e = getenv("TETRIS_GRAPH"); b->use_graph = (e && e[0] == '1'); }
     { const char* e = getenv("TETRIS_CHAIN_SPIN_LIMIT"); if (e && atoll(e) > 0) b->chain_spin_limit = (uint32_t)atoll(e); }
     b->nw = b->tint ? NWORDS_TINT : NWORDS;
@@ -1239,11 +1238,19 @@ int tetris_set_chained(tetris_batch* b, int on) {
     return TETRIS_OK;
 }
 
-int tetris_set_direct_dispatch(tetris_batch* b, int on) {
+static int default_direct_min() {
+    const char* off = getenv("TETRIS_DIRECT");
+    if (off && off[0] == '0') return 0;
+    const char* e = getenv("TETRIS_DIRECT_MIN");
+    const int v = e ? atoi(e) : 128;
+    return v < 1 ? 128 : v;
+}
+
+int tetris_set_direct_dispatch(tetris_batch* b, int min_launches) {
     int rc = check_batch(b);
     if (rc) return rc;
     if ((rc = finish_call(b))) return rc;
-    b->use_direct = on ? 1 : 0;
+    b->direct_min = min_launches < 0 ? default_direct_min() : min_launches;
     return TETRIS_OK;
 }
 
@@ -1269,19 +1276,22 @@ int tetris_debug_stall(tetris_batch* b, int which, int microseconds, int percent
     if (rc) return rc;
     if (which < -1 || which > 3 || microseconds < 0 || microseconds > 2000000 || percent < 0 || percent > 100) return fail(TETRIS_E_ARG, "which / microseconds / percent");
     const unsigned long long ticks = (unsigned long long)microseconds * 100ull;
-    if (which >= 0 && which < 3 && b->use_direct && b->aq.ok && which < b->chain_depth) {
-        // the batch launches through queues of its own (tetris_aql.h): the idle kernel goes to the one that stands for that stream
+    if (which >= 0 && which < 3 && b->direct_min > 0) {
+        // the device's own queues (tetris_aql.h), if they exist: the idle kernel goes to the one that stands for that stream as well —
+        // whichever way the next call's launches go, the ones with that number start late
         aql::Device* dev = aql::device_for(b->device);
-        if (!dev->ok || !dev->blocker.ok) return fail(TETRIS_E_HIP, "direct dispatch: no idle kernel in the loaded code object");
-        struct { const uint32_t* go; unsigned long long ticks; } args = {nullptr, ticks};
-        aql::Pending pd;
-        aql::write_dispatch(b->aq, pd, which, dev->blocker, &args, sizeof args, 1, HSA_FENCE_SCOPE_AGENT, HSA_FENCE_SCOPE_AGENT, hsa_signal_t{});
-        aql::ring(b->aq, pd);
-        return TETRIS_OK;
+        std::string why;
+        if (dev->ok && aql::make_queues(dev, why) && dev->blocker.ok) {
+            struct { const uint32_t* go; unsigned long long ticks; } args = {nullptr, ticks};
+            aql::Pending pd;
+            aql::write_dispatch(dev->qs, pd, which, dev->blocker, &args, sizeof args, 1, HSA_FENCE_SCOPE_AGENT, HSA_FENCE_SCOPE_AGENT, hsa_signal_t{});
+            aql::ring(dev->qs, pd);
+            b->direct_used = true;
+        }
     }
     if (which >= 0) {
         hipStream_t st = which == 3 ? b->stream : b->chain_stream[which % CHAIN_STREAMS];
-        if (which < 3) { b->chain_pending = true; b->stream_stalled = true; }
+        if (which < 3) b->chain_pending = true;
         hipLaunchKernelGGL(k_blocker, dim3(1), dim3(64), 0, st, (const uint32_t*)nullptr, ticks);
     } else {
         if (!b->stall_stream) HIP_TRY(hipStreamCreateWithFlags(&b->stall_stream, hipStreamNonBlocking));
@@ -2013,7 +2023,7 @@ static int chain_recover(tetris_batch* b) {
 // `group`: run-ahead of the whole call in launches (as for gate_launch); b->chain_epoch has not been advanced yet.
 static int rollout_direct(tetris_batch* b, aql::Device* dev, int launches, int steps_per_launch, uint32_t policy_seed, uint64_t first_step,
                           int ms, int group, float* elapsed_ms) {
-    aql::Queues& qs = b->aq;
+    aql::Queues& qs = dev->qs;
     const int depth = b->chain_depth;
     const aql::Kernel& kern = b->P == 1 ? dev->chain1 : dev->duo;
     const uint32_t blocks = b->P == 1 ? (uint32_t)((b->N + CHAIN_LANES - 1) / CHAIN_LANES) : (uint32_t)((b->N + 31) / 32);
@@ -2066,8 +2076,14 @@ static int rollout_direct(tetris_batch* b, aql::Device* dev, int launches, int s
         a.ms = ms; a.steps = steps_per_launch; a.policy_seed = policy_seed;
         a.first_step = first_step + (uint64_t)l * (uint64_t)steps_per_launch;
         a.chain = b->d_chain; a.epoch = epoch0 + (uint32_t)l + 1u; a.chain_spin_limit = b->chain_spin_limit;
-        static const int edge_scope = [] { const char* e = getenv("TETRIS_DIRECT_EDGE"); return e && !strcmp(e, "agent") ? HSA_FENCE_SCOPE_AGENT : HSA_FENCE_SCOPE_SYSTEM; }();   // (experiment knob)
-        aql::write_dispatch(qs, pd, k, kern, &a, sizeof a, blocks, first_on_queue ? edge_scope : mid_scope, last_on_queue ? edge_scope : mid_scope, sig);
+        // Fences.  The first packet of every queue ACQUIRES at system scope: whatever the host or an earlier kernel wrote (a restore
+        // through the copy engines, a step on the batch's stream) must not be met as a stale line in some XCD's L2.  No packet needs
+        // more than an agent-scope RELEASE: the chained kernels leave no dirty line behind — state and epoch words are written
+        // through (sc1), the counters are atomics performed at the memory side, the flag words live in host memory — and the
+        // host waits for the completion signals.  (TETRIS_DIRECT_EDGE=system / agent: both edges at that scope, experiment knob.)
+        static const int edge_knob = [] { const char* e = getenv("TETRIS_DIRECT_EDGE"); return !e ? -1 : (!strcmp(e, "agent") ? HSA_FENCE_SCOPE_AGENT : HSA_FENCE_SCOPE_SYSTEM); }();
+        const int acq_edge = edge_knob < 0 ? HSA_FENCE_SCOPE_SYSTEM : edge_knob, rel_edge = edge_knob < 0 ? HSA_FENCE_SCOPE_AGENT : edge_knob;
+        aql::write_dispatch(qs, pd, k, kern, &a, sizeof a, blocks, first_on_queue ? acq_edge : mid_scope, last_on_queue ? rel_edge : mid_scope, sig);
         // the first launches go out one by one (the GPU is idle), later ones eight at a time (one fence + read back per eight)
         if (++unflushed >= 8 || l < 2 * depth || l == launches - 1) { aql::ring(qs, pd); unflushed = 0; }
     }
@@ -2200,20 +2216,19 @@ int tetris_rollout_launch(tetris_batch* b, int launches, int steps_per_launch, u
         group = 1 << 20;
     }
     b->last_direct = false;
-    if (chained && !prequeue && b->use_direct && !b->stream_stalled) {
-        // the batch's own queues (tetris_aql.h); anything that keeps them from being set up switches them off for this batch
+    if (chained && !prequeue && b->direct_min > 0 && launches >= b->direct_min) {
+        // the device's own queues (tetris_aql.h); anything that keeps them from being set up switches them off for this batch
         aql::Device* dev = aql::device_for(b->device);
         std::string why = dev->why;
-        if (dev->ok && aql::make_queues(dev, b->aq, b->chain_depth, why)) {
+        if (dev->ok && aql::make_queues(dev, why)) {
             if (b->home_async) { HIP_TRY(hipStreamSynchronize(home)); }      // what the batch's stream still holds comes first
-            b->last_direct = true;
+            b->last_direct = true; b->direct_used = true;
             if (getenv("TETRIS_TIMING")) fprintf(stderr, "[tetris timing] call entry -> direct dispatch %.1f us\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_entry).count() * 1e6);
             return rollout_direct(b, dev, launches, steps_per_launch, policy_seed, first_step, ms, group, elapsed_ms);
         }
-        b->use_direct = 0;
+        b->direct_min = 0;
         if (getenv("TETRIS_TIMING")) fprintf(stderr, "[tetris] direct dispatch is off: %s\n", why.c_str());
     }
-    b->stream_stalled = false;
     struct GoGuard {                              // (no return path leaves the blocker waiting for its flag)
         tetris_batch* b; bool armed;
         ~GoGuard() { if (armed) ((volatile uint32_t*)b->flags)[F_GO] = 1; }

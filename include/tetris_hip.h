@@ -251,19 +251,21 @@ int tetris_rollout_launch(tetris_batch *b, int launches, int steps_per_launch, u
  * priorities); the batch's own stream has the default priority.
  * on = 0: every launch on the batch's one stream.                                                                       */
 int tetris_set_chained(tetris_batch *b, int on);
-/* DIRECT DISPATCH of the chained launches (default on).  A chained launch takes the GPU 4 us; hipLaunchKernel costs the calling
- * thread 2.4-4.2 us of it, depending on the process.  With direct dispatch the library writes the launches' AQL packets itself, into
- * HSA user-mode queues of the batch's own (one per chain stream; created on the first chained call): 0.2-0.5 us of host time per
- * launch, and a call's first kernel starts ~3 us sooner.  Same kernels, same machine code (the gfx950 code object is taken from this
- * library's own fat binary and loaded through the HSA loader), same hand-over protocol, same results; the queues' launches are
- * ordered like a stream's (barrier bit), the first packet of a queue acquires and the last releases at system scope.  A call that
- * goes this way first waits for what the batch's stream still holds and returns with its launches retired, like every chained call.
- * If the queues cannot be set up (no HSA agent for the HIP device, no host-visible device memory for the kernel arguments, code
- * object not found), the batch silently keeps launching through its streams.  on = 0: streams.  TETRIS_DIRECT=0 in the environment:
- * batches are created with it off.  Pre-queued calls (TETRIS_PREQUEUE) and the call after tetris_debug_stall held a chain stream go
- * through the streams.                                                                                                   */
-int tetris_set_direct_dispatch(tetris_batch *b, int on);
-/* 1 if the batch's last tetris_rollout_launch / tetris_rollout_random went through its own queues, 0 if through streams */
+/* DIRECT DISPATCH of long chained calls.  A chained launch takes the GPU 4 us; hipLaunchKernel costs the calling thread 2.4-4.2 us
+ * of it, depending on the process.  Calls of at least `min_launches` launches (default 128) therefore do not go through
+ * hipLaunchKernel: the library writes their AQL packets itself, into three HSA user-mode queues of its own per GPU (created on the
+ * first such call; shared by the device's batches, whose chained calls exclude each other anyway): 0.2-0.5 us of host time per
+ * launch, no helper threads, 1.5-2 % shorter calls.  Same kernels, same machine code (the gfx950 code object is taken from this
+ * library's own fat binary and loaded through the HSA loader), same hand-over protocol, same results; a queue's launches are
+ * ordered like a stream's (barrier bit), its first packet acquires at system scope.  Such a call first waits for what the batch's
+ * stream still holds and returns with its launches retired, like every chained call.  Shorter calls stay on the streams: a queue that
+ * has been idle takes 10 us to start its first wave, and in a 20-launch call the streams came out ahead
+ * (profiles/r03/direct_dispatch.txt).  If the queues cannot be set up (no HSA agent for the HIP device, no host-visible device
+ * memory for the kernel arguments, code object not found), the batch keeps launching through its streams.
+ * min_launches = 0: never; n > 0: calls of at least n launches; < 0: the default (TETRIS_DIRECT_MIN in the environment, else 128;
+ * TETRIS_DIRECT=0: batches are created with 0).  Pre-queued calls (TETRIS_PREQUEUE) go through the streams.              */
+int tetris_set_direct_dispatch(tetris_batch *b, int min_launches);
+/* 1 if the batch's last tetris_rollout_launch / tetris_rollout_random went through those queues, 0 if through streams   */
 int tetris_rollout_was_direct(tetris_batch *b);
 /* polls of its predecessor's epoch word after which a waiting wave of a chained launch gives up (0 = the default, 2^22);
  * one poll is an agent-scope load and a short sleep, about 0.5 us.                                                     */
@@ -271,7 +273,8 @@ int tetris_set_chain_spin_limit(tetris_batch *b, uint32_t polls);
 /* MEASUREMENT AID: the GPU's shader clock of the moment in kHz (a 50 us probe kernel on the batch's stream; synchronous).      */
 int tetris_debug_clock_khz(tetris_batch *b, int *khz);
 /* TEST AID for the give-up path above (nothing in the product calls it): enqueues a kernel that idles for `microseconds` —
- * which = 0..2: on that one of the three chain streams, so the launches the next rollout call puts there start late;
+ * which = 0..2: on that one of the three chain streams (and of the device's own queues, see tetris_set_direct_dispatch), so the
+ * launches the next rollout call puts there start late;
  * which = 3: on the batch's stream; which = -1: on a stream of its own, as workgroups that hold `percent` % of the device's
  * wave slots meanwhile (a co-tenant).  Asynchronous.                                                                   */
 int tetris_debug_stall(tetris_batch *b, int which, int microseconds, int percent);
@@ -292,9 +295,10 @@ int tetris_debug_stall(tetris_batch *b, int which, int microseconds, int percent
  *   TETRIS_ENQUEUE_THREADS_MIN=<n>  chained calls of at least n launches (default 256) are enqueued by one host thread per chain
  *                       stream (a launch costs the host 2.7-4.0 us, the GPU needs one every 4.0); 0 = always one thread
  *   TETRIS_GATE_GROUP=<n>  launches per run-ahead group (default 120: at most 241 in flight), 8..120
- *   TETRIS_DIRECT=0     batches are created with direct dispatch off (tetris_set_direct_dispatch)
- *   TETRIS_DIRECT_FENCE=none  (experiment) direct dispatch: fence scope "none" instead of "agent" on the packets between a queue's
- *                       first and last
+ *   TETRIS_DIRECT=0     batches are created with direct dispatch off; TETRIS_DIRECT_MIN=<n>: its default threshold
+ *                       (tetris_set_direct_dispatch)
+ *   TETRIS_DIRECT_FENCE=none, TETRIS_DIRECT_EDGE=agent|system, TETRIS_DIRECT_PRIO=high  (experiments) direct dispatch: fence scope of
+ *                       the packets between a queue's first and last / of its first and last packet; queue priority
  *   TETRIS_TIMING=1     tetris_rollout_launch prints its host-side costs (enqueue per launch, gate waits, until drained) to stderr */
 /* 1 if tetris_rollout_launch / tetris_rollout_random would chain launches of `steps_per_launch` steps on this batch, 0 if not
  * (switched off — by the caller or by a fall-back —, caller-owned stream, split or colour batch, or not even two launches fit

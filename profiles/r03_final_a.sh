@@ -13,6 +13,14 @@ timeout -k 10 200 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.
 timeout -k 10 300 python bench.py > $O/bench_p1_s1.json 2> $O/bench_p1_s1.err
 timeout -k 10 300 python bench.py --steps 20 --warmup 5 > $O/bench_p1_s1_driver_flags.json 2>/dev/null
 timeout -k 10 200 python bench.py --players 2 --cpu-seconds 0 > $O/bench_p2_s1.json 2>/dev/null
+# the same lines with the launches going through hipLaunchKernel on streams instead of the batch's own queues
+TETRIS_DIRECT=0 timeout -k 10 300 python bench.py --cpu-seconds 0 > $O/bench_p1_s1_streams.json 2>/dev/null
+TETRIS_DIRECT=0 timeout -k 10 300 python bench.py --steps 20 --warmup 5 --cpu-seconds 0 > $O/bench_p1_s1_driver_flags_streams.json 2>/dev/null
+TETRIS_DIRECT=0 timeout -k 10 200 python bench.py --players 2 --cpu-seconds 0 > $O/bench_p2_s1_streams.json 2>/dev/null
+for i in 1 2 3; do timeout -k 10 300 python bench.py --steps 20 --warmup 5 --cpu-seconds 0 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('driver flags, direct :', round(d['value']/1e9,2), 'G', round(d['ms_per_step']*1e3,3), 'us')"; TETRIS_DIRECT=0 timeout -k 10 300 python bench.py --steps 20 --warmup 5 --cpu-seconds 0 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('driver flags, streams:', round(d['value']/1e9,2), 'G', round(d['ms_per_step']*1e3,3), 'us')"; done > $O/driver_flags_ab.txt 2>&1
+cat $O/driver_flags_ab.txt
+{ timeout -k 10 200 python profiles/short_calls3.py 20 1 40; timeout -k 10 200 python profiles/short_calls3.py 20 1 40 1; timeout -k 10 200 python profiles/short_calls3.py 2048 1 6; timeout -k 10 200 python profiles/short_calls3.py 20 2 40; timeout -k 10 200 python profiles/short_calls3.py 2048 2 6; } 2>/dev/null | grep "^K=" > $O/direct_vs_streams.txt
+cat $O/direct_vs_streams.txt
 TETRIS_NO_CHAIN=1 timeout -k 10 200 python bench.py --cpu-seconds 0 > $O/bench_p1_s1_unchained.json 2>/dev/null
 TETRIS_NO_CHAIN=1 timeout -k 10 200 python bench.py --players 2 --cpu-seconds 0 > $O/bench_p2_s1_unchained.json 2>/dev/null
 timeout -k 10 200 python bench.py --steps 256 --warmup 8 --steps-per-launch 32 --cpu-seconds 0 > $O/bench_p1_s32.json 2>/dev/null

@@ -19,13 +19,13 @@ P = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 30
 sh = mod.ShardedRollout(65536, P, 20, 10, rank=0, world=1, device=0)
 for direct in (True, False):
-    sh.batch.set_direct_dispatch(direct)
+    sh.batch.set_direct_dispatch(direct, min_launches=1)
     sh.run(256, 1)
 res = {True: [], False: []}
 ev = {True: [], False: []}
 for rep in range(reps):
     for direct in (True, False):
-        sh.batch.set_direct_dispatch(direct)
+        sh.batch.set_direct_dispatch(direct, min_launches=1)
         sh.run(5, 1)
         r = sh.run(K, 1)
         assert sh.batch.rollout_was_direct() == direct

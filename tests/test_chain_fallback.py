@@ -40,7 +40,7 @@ def test_a_late_predecessor_makes_the_call_fall_back_and_the_results_stay_exact(
     eng.set_chain_spin_limit(2000)                         # ~1 ms
     before = eng.rollout_totals()                          # (synchronises: nothing may drain the streams between the stall and the launches)
     eng.debug_stall(1, 30000)                              # the second launch of the next call (and every third after it) starts 30 ms late
-    stalled = 50 if P == 2 else 300                        # (300: the call that is enqueued by one host thread per stream)
+    stalled = 50 if P == 2 else 300                        # (300: a call that goes through the library's own queues; 50: through the streams)
     eng.rollout_launch(stalled, 1, first_step=40)
     total += eng.rollout_totals() - before
     assert eng.take_errors() == FELL_BACK

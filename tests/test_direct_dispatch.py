@@ -23,11 +23,12 @@ def _same(eng, ref, n, where=""):
 
 @pytest.mark.parametrize("P,n", [(1, 65536), (2, 65536), (1, 1000), (2, 33)])
 def test_direct_dispatch_is_what_runs_and_is_bit_exact(P, n):
-    """Default batch: chained calls go through the batch's own queues (asserted, not assumed); 150 launches in calls of 1, 2, 3, 7, 20
+    """Chained calls go through the library's own queues (asserted, not assumed); 150 launches in calls of 1, 2, 3, 7, 20
     and 117 launches (fewer launches than queues; a call's first and last packet on the same queue) against the oracle."""
     seeds = orc.episode_seed(np.arange(n), 0)
     eng, ref = engines.make("hip", n, P, seeds=seeds), engines.make("oracle", n, P, seeds=seeds)
     assert eng.rollout_is_chained(1)
+    eng.set_direct_dispatch(True, min_launches=1)          # (by default only calls of >= 128 launches go this way)
     total, step = np.zeros(4, np.uint64), 0
     for launches in (1, 2, 3, 7, 20, 117):
         c, ms = eng.rollout_random(launches, 1, first_step=step)
@@ -50,13 +51,13 @@ def test_queues_and_streams_take_turns(P):
     eng, ref = engines.make("hip", n, P, seeds=seeds), engines.make("oracle", n, P, seeds=seeds)
     total, step = np.zeros(4, np.uint64), 0
     for rep in range(6):
-        eng.set_direct_dispatch(rep % 2 == 0)
+        eng.set_direct_dispatch(rep % 2 == 0, min_launches=1)
         c, _ = eng.rollout_random(13 + rep, 1, first_step=step)
         assert eng.rollout_was_direct() == (rep % 2 == 0)
         total += c
         step += 13 + rep
         eng.observe(np.arange(0, n, 7, dtype=np.int32))       # a kernel + copy on the batch's stream in between
-    eng.set_direct_dispatch(True)
+    eng.set_direct_dispatch(True, min_launches=1)
     blob = eng.snapshot()
     eng.rollout_random(9, 1, first_step=step)              # moves on ...
     eng.restore(blob)                                      # ... and is put back by the host
@@ -75,13 +76,13 @@ def test_a_long_call_wraps_the_argument_ring_and_the_flow_control():
     seeds = orc.episode_seed(np.arange(n), 0)
     eng, ref = engines.make("hip", n, 1, seeds=seeds), engines.make("oracle", n, 1, seeds=seeds)
     c, _ = eng.rollout_random(5000, 1)
-    assert eng.rollout_was_direct()
+    assert eng.rollout_was_direct()                        # the default: calls of >= 128 launches
     _, want = ref.rollout_random(5000, threads=THREADS)
     assert c.tolist() == want.tolist()
     _same(eng, ref, n)
 
 
-def test_same_results_with_direct_dispatch_off():
+def test_same_results_with_direct_dispatch_off_and_short_calls_stay_on_the_streams():
     n = 8192
     seeds = orc.episode_seed(np.arange(n), 0)
     a, b = engines.make("hip", n, 2, seeds=seeds), engines.make("hip", n, 2, seeds=seeds)
@@ -91,3 +92,5 @@ def test_same_results_with_direct_dispatch_off():
     assert a.rollout_was_direct() and not b.rollout_was_direct()
     assert ca.tolist() == cb.tolist()
     assert np.array_equal(a.snapshot(), b.snapshot())
+    a.rollout_random(20, 1, first_step=200)
+    assert not a.rollout_was_direct()                      # below the default threshold

@@ -185,19 +185,23 @@ def test_chain_depth_two_where_three_launches_do_not_fit():
         engines.assert_same_state(eng, ref, idx=np.arange(lo, lo + 8192, dtype=np.int32), where=f"games {lo}..")
 
 
-@pytest.mark.parametrize("P", [1, 2])
-def test_long_chained_calls_are_enqueued_by_one_thread_per_stream_and_stay_bit_exact(P):
-    """From 256 launches per call on, tetris_rollout_launch enqueues every chain stream's launches from a thread of its own
-    (a launch costs the host up to 4 us, the GPU needs one every 4: one thread cannot always keep up).  Two calls of 700 and 300
-    launches at 64k games, then the single-threaded path again: counters and every board against the oracle."""
+@pytest.mark.parametrize("P,direct", [(1, False), (2, False), (1, True)])
+def test_long_chained_calls_stay_bit_exact_on_either_launch_path(P, direct):
+    """Long calls on the stream path: from 256 launches per call on, tetris_rollout_launch enqueues every chain stream's launches
+    from a thread of its own (a launch costs the host up to 4 us, the GPU needs one every 4: one thread cannot always keep up).
+    By default such calls do not go through hipLaunchKernel at all but through the library's own queues (direct = True).  Two calls
+    of 700 and 300 launches at 64k games, then a short one: counters and every board against the oracle."""
     n = 65536
     seeds = orc.episode_seed(np.arange(n), 0)
     eng, ref = engines.make("hip", n, P, seeds=seeds), engines.make("oracle", n, P, seeds=seeds)
     assert eng.rollout_is_chained(1)
+    if not direct:
+        eng.set_direct_dispatch(False)
     total = np.zeros(4, np.uint64)
     step = 0
     for launches in (700, 300, 40):
         c, _ = eng.rollout_random(launches, 1, first_step=step)
+        assert eng.rollout_was_direct() == (direct and launches >= 128)
         total += c
         step += launches
     assert eng.take_errors() == 0
