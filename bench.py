@@ -287,10 +287,13 @@ def main():
         # longer than W = 5 warm-up launches.  So the device — not the measured batch — is warmed first: the same kind of
         # launches on a scratch batch of the same shape, which is then thrown away.  Untimed, stated in the JSON line.
         scratch = sharded.ShardedRollout(N, P, args.height, 10, rank=rank, world=world, device=local_rank, dist=None)
+        # (calls of the timed call's own length, at most 256 launches: the library sends short and long calls down different launch
+        # paths — streams / its own queues, include/tetris_hip.h: tetris_set_direct_dispatch — and the path that is timed is the one warmed)
+        per_call = max(1, min(256, args.steps))
         t_end = time.perf_counter() + args.precondition_ms * 1e-3
         while time.perf_counter() < t_end:
-            scratch.batch.rollout_launch(256, S, first_step=precondition_launches * S)
-            precondition_launches += 256
+            scratch.batch.rollout_launch(per_call, S, first_step=precondition_launches * S)
+            precondition_launches += per_call
         scratch.close()
     if args.warmup > 0:
         shard.run(args.warmup, S)                     # untimed warm-up

@@ -2216,18 +2216,21 @@ int tetris_rollout_launch(tetris_batch* b, int launches, int steps_per_launch, u
         group = 1 << 20;
     }
     b->last_direct = false;
-    if (chained && !prequeue && b->direct_min > 0 && launches >= b->direct_min) {
-        // the device's own queues (tetris_aql.h); anything that keeps them from being set up switches them off for this batch
+    if (chained && !prequeue && b->direct_min > 0) {
+        // the device's own queues (tetris_aql.h); anything that keeps them from being set up switches them off for this batch.  They
+        // are made by the first chained call of ANY length (loading the code object takes ~15 ms: a warm-up call's business,
+        // not that of the first long call).
         aql::Device* dev = aql::device_for(b->device);
         std::string why = dev->why;
-        if (dev->ok && aql::make_queues(dev, why)) {
+        if (!(dev->ok && aql::make_queues(dev, why))) {
+            b->direct_min = 0;
+            if (getenv("TETRIS_TIMING")) fprintf(stderr, "[tetris] direct dispatch is off: %s\n", why.c_str());
+        } else if (launches >= b->direct_min) {
             if (b->home_async) { HIP_TRY(hipStreamSynchronize(home)); }      // what the batch's stream still holds comes first
             b->last_direct = true; b->direct_used = true;
             if (getenv("TETRIS_TIMING")) fprintf(stderr, "[tetris timing] call entry -> direct dispatch %.1f us\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_entry).count() * 1e6);
             return rollout_direct(b, dev, launches, steps_per_launch, policy_seed, first_step, ms, group, elapsed_ms);
         }
-        b->direct_min = 0;
-        if (getenv("TETRIS_TIMING")) fprintf(stderr, "[tetris] direct dispatch is off: %s\n", why.c_str());
     }
     struct GoGuard {                              // (no return path leaves the blocker waiting for its flag)
         tetris_batch* b; bool armed;
