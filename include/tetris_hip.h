@@ -292,7 +292,7 @@ int tetris_debug_stall(tetris_batch *b, int which, int microseconds, int percent
  *                       serialised by the stream (what per-dispatch PMC counters need: profiles/pmc_summary.py)
  *   TETRIS_EXT_EVENTS=0 chained calls record their timing / join events as packets of their own instead of attaching them to the
  *                       first and last kernels (hipExtLaunchKernel, the default)
- *   TETRIS_ENQUEUE_THREADS_MIN=<n>  chained calls of at least n launches (default 256) are enqueued by one host thread per chain
+ *   TETRIS_ENQUEUE_THREADS_MIN=<n>  (stream path) chained calls of at least n launches (default 256) are enqueued by one host thread per chain
  *                       stream (a launch costs the host 2.7-4.0 us, the GPU needs one every 4.0); 0 = always one thread
  *   TETRIS_GATE_GROUP=<n>  launches per run-ahead group (default 120: at most 241 in flight), 8..120
  *   TETRIS_DIRECT=0     batches are created with direct dispatch off; TETRIS_DIRECT_MIN=<n>: its default threshold
