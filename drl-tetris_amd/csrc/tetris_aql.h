@@ -21,9 +21,9 @@
 // The queues belong to the DEVICE, not to a batch (chained calls of a device's batches exclude each other anyway): three more
 // hardware queues per process and GPU, however many batches there are.
 // Only calls of at least `direct_min` launches (default 128) go this way.  A queue that has been idle for ~100 us takes 10 us from
-// doorbell to first wave instead of 5 (profiles/r03/aql_probe.txt), as a stream's does, and in calls as short as the driver's 20
-// launches the stream path — whose first launches the runtime has to prepare anyway while the queue wakes — came out 5-12 us
-// ahead (profiles/r03/direct_dispatch.txt); from a few hundred launches on the queues are 1.5-2 % faster and need no helper threads.
+// doorbell to first wave instead of 5 (profiles/r03/aql_probe.txt), as a stream's does; in calls as short as the driver's 20
+// launches the two paths are level (profiles/r03/direct_dispatch.txt, (6)); from a few hundred launches on the queues are
+// 1.5-2 % faster and need no helper threads.
 // Anything that fails while setting this up switches it off for the batch (the stream path remains); TETRIS_DIRECT=0 in the
 // environment or tetris_set_direct_dispatch(b, 0) do the same by hand.
 #pragma once

@@ -815,7 +815,7 @@ struct tetris_batch {
     uint32_t* d_shadow = nullptr;        // split mode, side 1
     hipStream_t own_stream = nullptr;
     // chained launches (k_chain): two extra streams, one epoch word per wave, the number of the last chained launch
-    hipStream_t chain_stream[CHAIN_STREAMS] = {};
+    hipStream_t chain_stream[CHAIN_STREAMS] = {};     // the device's (device_chain_streams): shared with its other batches, never destroyed
     hipEvent_t chain_ev[CHAIN_STREAMS + 1] = {};      // [k]: end of chain stream k's last launch (join); [CHAIN_STREAMS]: fork from the batch's stream
     hipEvent_t worker_gate_ev[CHAIN_STREAMS][2] = {}; // run-ahead gates of the per-stream enqueue threads (tetris_rollout_launch)
     uint32_t* d_chain = nullptr;
@@ -1120,7 +1120,6 @@ int tetris_destroy(tetris_batch* b) {
     for (hipEvent_t e : b->gate_ev) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : b->chain_ev) if (e) (void)hipEventDestroy(e);
     for (auto& pair : b->worker_gate_ev) for (hipEvent_t e : pair) if (e) (void)hipEventDestroy(e);
-    for (hipStream_t st : b->chain_stream) if (st) (void)hipStreamDestroy(st);
     (void)hipFree(b->d_chain);
     free(b->h_chain);
     if (b->stall_stream) { (void)hipStreamSynchronize(b->stall_stream); (void)hipStreamDestroy(b->stall_stream); }
@@ -1132,6 +1131,34 @@ int tetris_destroy(tetris_batch* b) {
     if (b->own_stream) (void)hipStreamDestroy(b->own_stream);
     delete b;
     return TETRIS_OK;
+}
+
+// The chain streams of a device, made once and shared by all its batches (chained calls of a device's batches exclude each
+// other: chain_acquire).  Per batch they cost three more streams each, and the runtime deals streams onto few hardware
+// queues: a batch created after two others ran its chained 20-launch calls at 11-13 us per launch instead of 5, its streams
+// sharing queues (profiles/r03/direct_dispatch.txt).
+// Every chain stream gets a stream priority of its own.  Not for the priorities' sake: the runtime keeps one hardware queue per
+// priority level apart from the four (GPU_MAX_HW_QUEUES) it deals ordinary streams onto in turn, and two chain streams on ONE
+// hardware queue do not overlap (measured with GPU_MAX_HW_QUEUES=2: 5.07 us per launch with equal priorities, 3.99 with three
+// different ones; with four queues 4.00 either way: profiles/r02/hw_queues.txt).  TETRIS_CHAIN_PRIO=0: equal priorities.
+static std::mutex g_dev_streams_mutex;
+static hipStream_t g_dev_streams[64][CHAIN_STREAMS] = {};
+static hipError_t device_chain_streams(int device, hipStream_t out[CHAIN_STREAMS]) {
+    std::lock_guard<std::mutex> lock(g_dev_streams_mutex);
+    hipStream_t* st = g_dev_streams[device & 63];
+    if (!st[0]) {
+        int lo = 0, hi = 0;
+        const char* e = getenv("TETRIS_CHAIN_PRIO");
+        const bool spread = !(e && e[0] == '0') && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo - hi + 1 >= CHAIN_STREAMS;
+        hipStream_t made[CHAIN_STREAMS] = {};
+        for (int k = 0; k < CHAIN_STREAMS; k++) {
+            const hipError_t ce = spread ? hipStreamCreateWithPriority(&made[k], hipStreamNonBlocking, hi + k) : hipStreamCreateWithFlags(&made[k], hipStreamNonBlocking);
+            if (ce != hipSuccess) { for (int j = 0; j < k; j++) (void)hipStreamDestroy(made[j]); return ce; }
+        }
+        for (int k = 0; k < CHAIN_STREAMS; k++) st[k] = made[k];
+    }
+    for (int k = 0; k < CHAIN_STREAMS; k++) out[k] = st[k];
+    return hipSuccess;
 }
 
 static int create_impl(tetris_batch** out, int n_games, int n_players, int height, int width, const uint8_t piece_map[7],
@@ -1178,18 +1205,9 @@ static int create_impl(tetris_batch** out, int n_games, int n_players, int heigh
     b->own_stream = b->stream;
     CREATE_TRY(hipEventCreate(&b->ev0));
     CREATE_TRY(hipEventCreate(&b->ev1));
-    {
-        // Every chain stream gets a stream priority of its own.  Not for the priorities' sake: the runtime keeps one hardware queue per
-        // priority level apart from the four (GPU_MAX_HW_QUEUES) it deals ordinary streams onto in turn, and two chain streams on ONE
-        // hardware queue do not overlap (measured with GPU_MAX_HW_QUEUES=2: 5.07 us per launch with equal priorities, 3.99 with three
-        // different ones; with four queues 4.00 either way: profiles/r02/hw_queues.txt).  TETRIS_CHAIN_PRIO=0: equal priorities.
-        int lo = 0, hi = 0;
-        const char* e = getenv("TETRIS_CHAIN_PRIO");
-        const bool spread = !(e && e[0] == '0') && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo - hi + 1 >= CHAIN_STREAMS;
-        for (int k = 0; k < CHAIN_STREAMS; k++) {
-            if (spread) CREATE_TRY(hipStreamCreateWithPriority(&b->chain_stream[k], hipStreamNonBlocking, hi + k));
-            else CREATE_TRY(hipStreamCreateWithFlags(&b->chain_stream[k], hipStreamNonBlocking));
-        }
+    {   // the chain streams belong to the DEVICE (device_chain_streams below): every batch of a device uses the same three
+        hipError_t ce = device_chain_streams(device, b->chain_stream);
+        CREATE_TRY(ce);
     }
     for (int k = 0; k < CHAIN_STREAMS + 1; k++) CREATE_TRY(hipEventCreateWithFlags(&b->chain_ev[k], hipEventDisableTiming));
     for (int k = 0; k < CHAIN_STREAMS; k++) for (int j = 0; j < 2; j++) CREATE_TRY(hipEventCreateWithFlags(&b->worker_gate_ev[k][j], hipEventDisableTiming));

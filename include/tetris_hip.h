@@ -246,6 +246,7 @@ int tetris_rollout_launch(tetris_batch *b, int launches, int steps_per_launch, u
  * tetris_take_errors reports TETRIS_ERR_CHAIN_FELL_BACK once, and chained launches stay off for the batch until
  * tetris_set_chained(b, 1).  On a GPU that the batch shares with other work, switch chaining off up front:
  * tetris_set_chained(b, 0) — or TETRIS_NO_CHAIN=1 — costs 5.7 us per launch instead of 4.0 and cannot starve anything.
+ * The three chain streams belong to the device and are shared by all its batches (their chained calls exclude each other).
  * Side effect a host application may notice: the three streams are created with three different stream priorities (that is how
  * the HIP runtime is made to keep them on three hardware queues, where alone they overlap; TETRIS_CHAIN_PRIO=0: equal
  * priorities); the batch's own stream has the default priority.
@@ -259,7 +260,7 @@ int tetris_set_chained(tetris_batch *b, int on);
  * library's own fat binary and loaded through the HSA loader), same hand-over protocol, same results; a queue's launches are
  * ordered like a stream's (barrier bit), its first packet acquires at system scope.  Such a call first waits for what the batch's
  * stream still holds and returns with its launches retired, like every chained call.  Shorter calls stay on the streams: a queue that
- * has been idle takes 10 us to start its first wave, and in a 20-launch call the streams came out ahead
+ * has been idle takes 10 us to start its first wave, as a stream does, and in a 20-launch call the two are level
  * (profiles/r03/direct_dispatch.txt).  If the queues cannot be set up (no HSA agent for the HIP device, no host-visible device
  * memory for the kernel arguments, code object not found), the batch keeps launching through its streams.
  * min_launches = 0: never; n > 0: calls of at least n launches; < 0: the default (TETRIS_DIRECT_MIN in the environment, else 128;
