@@ -59,6 +59,7 @@ _SIGNATURES = {
     "tetris_rollout_is_chained": (C.c_int, [C.c_void_p, C.c_int]),
     "tetris_set_direct_dispatch": (C.c_int, [C.c_void_p, C.c_int]),
     "tetris_rollout_was_direct": (C.c_int, [C.c_void_p]),
+    "tetris_debug_code_objects": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_uint64)]),
     "tetris_set_chain_spin_limit": (C.c_int, [C.c_void_p, C.c_uint32]),
     "tetris_debug_stall": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "tetris_debug_clock_khz": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -1272,6 +1272,17 @@ int tetris_set_direct_dispatch(tetris_batch* b, int min_launches) {
     return TETRIS_OK;
 }
 
+int tetris_debug_code_objects(int* count, uint64_t* bytes) {
+    if (!count || !bytes) return fail(TETRIS_E_ARG, "count / bytes is NULL");
+    std::vector<std::vector<char>> images;
+    std::string why;
+    *count = 0; *bytes = 0;
+    if (!aql::own_code_objects(images, why)) return TETRIS_OK;      // (none: the caller sees count == 0)
+    *count = (int)images.size();
+    for (auto& img : images) *bytes += img.size();
+    return TETRIS_OK;
+}
+
 int tetris_rollout_was_direct(tetris_batch* b) {
     int rc = check_batch(b, false);
     if (rc) return rc;

@@ -268,6 +268,9 @@ int tetris_set_chained(tetris_batch *b, int on);
 int tetris_set_direct_dispatch(tetris_batch *b, int min_launches);
 /* 1 if the batch's last tetris_rollout_launch / tetris_rollout_random went through those queues, 0 if through streams   */
 int tetris_rollout_was_direct(tetris_batch *b);
+/* TEST AID (needs no GPU): the gfx950 code objects direct dispatch would load — found in this library's own fat binary —: their
+ * number and total size in bytes.  0 objects = direct dispatch cannot work with this build (e.g. a compressed offload bundle).  */
+int tetris_debug_code_objects(int *count, uint64_t *bytes);
 /* polls of its predecessor's epoch word after which a waiting wave of a chained launch gives up (0 = the default, 2^22);
  * one poll is an agent-scope load and a short sleep, about 0.5 us.                                                     */
 int tetris_set_chain_spin_limit(tetris_batch *b, uint32_t polls);

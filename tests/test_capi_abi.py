@@ -32,6 +32,17 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert orc.RECORD == pkg.RECORD            # checker and product agree on the record layout
 
 
+def test_the_library_finds_its_own_gfx950_code_objects():
+    """Direct dispatch (include/tetris_hip.h: tetris_set_direct_dispatch) loads the kernels through the HSA loader from the code
+    objects inside the library's own fat binary; if a toolchain change hid them (a compressed offload bundle, say), long rollout
+    calls would silently go back to the streams.  Two translation units -> two gfx950 code objects, found without a GPU."""
+    import ctypes as C
+    lib = ge.package().load_library()
+    count, size = C.c_int(-1), C.c_uint64(0)
+    assert lib.tetris_debug_code_objects(C.byref(count), C.byref(size)) == 0
+    assert count.value == 2 and size.value > 1 << 20
+
+
 def test_no_cpu_fallback_without_device():
     pkg = ge.package()
     if ge.gpu_available():
