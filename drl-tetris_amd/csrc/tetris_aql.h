@@ -20,10 +20,11 @@
 //    outstanding (the margin of the RNG tables is sized for that, as for the stream path's gate).
 // The queues belong to the DEVICE, not to a batch (chained calls of a device's batches exclude each other anyway): three more
 // hardware queues per process and GPU, however many batches there are.
-// Only calls of at least `direct_min` launches (default 128) go this way.  A queue that has been idle for ~100 us takes 10 us from
+// Only calls of at least `direct_min` launches (default 16) go this way.  A queue that has been idle for ~100 us takes 10 us from
 // doorbell to first wave instead of 5 (profiles/r03/aql_probe.txt), as a stream's does; in calls as short as the driver's 20
-// launches the two paths are level (profiles/r03/direct_dispatch.txt, (6)); from a few hundred launches on the queues are
-// 1.5-2 % faster and need no helper threads.
+// launches the two paths are level for one player (the queues' times spread less: they do not feel the host's launch cost) and
+// the queues 5-8 % ahead for two (profiles/r03/direct_dispatch.txt, (6)); from a few hundred launches on they are 1.5-2 % faster
+// and need no helper threads.  A call of a handful of launches is not worth three system-scope acquires.
 // Anything that fails while setting this up switches it off for the batch (the stream path remains); TETRIS_DIRECT=0 in the
 // environment or tetris_set_direct_dispatch(b, 0) do the same by hand.
 #pragma once

@@ -832,7 +832,7 @@ struct tetris_batch {
     uint32_t* h_chain = nullptr;         // host copy of the epoch words (chain_recover)
     hipStream_t stall_stream = nullptr;  // tetris_debug_stall(.., -1, ..)
     // direct dispatch of the chained launches (tetris_aql.h): queues of the batch's own; off when anything about it failed
-    int direct_min = 128;                // calls of at least this many launches go through the device's own queues; 0: never (TETRIS_DIRECT=0 / TETRIS_DIRECT_MIN, tetris_set_direct_dispatch)
+    int direct_min = 16;                 // calls of at least this many launches go through the device's own queues; 0: never (TETRIS_DIRECT=0 / TETRIS_DIRECT_MIN, tetris_set_direct_dispatch)
     bool last_direct = false;            // the last rollout call went through those queues
     bool direct_used = false;            // ... and so did some call of this batch (its destruction waits for the queues)
     bool home_async = false;             // asynchronous (_dev) work was enqueued on the batch's stream since the last drain
@@ -1260,8 +1260,8 @@ static int default_direct_min() {
     const char* off = getenv("TETRIS_DIRECT");
     if (off && off[0] == '0') return 0;
     const char* e = getenv("TETRIS_DIRECT_MIN");
-    const int v = e ? atoi(e) : 128;
-    return v < 1 ? 128 : v;
+    const int v = e ? atoi(e) : 16;
+    return v < 1 ? 16 : v;
 }
 
 int tetris_set_direct_dispatch(tetris_batch* b, int min_launches) {

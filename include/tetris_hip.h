@@ -253,17 +253,17 @@ int tetris_rollout_launch(tetris_batch *b, int launches, int steps_per_launch, u
  * on = 0: every launch on the batch's one stream.                                                                       */
 int tetris_set_chained(tetris_batch *b, int on);
 /* DIRECT DISPATCH of long chained calls.  A chained launch takes the GPU 4 us; hipLaunchKernel costs the calling thread 2.4-4.2 us
- * of it, depending on the process.  Calls of at least `min_launches` launches (default 128) therefore do not go through
+ * of it, depending on the process.  Calls of at least `min_launches` launches (default 16) therefore do not go through
  * hipLaunchKernel: the library writes their AQL packets itself, into three HSA user-mode queues of its own per GPU (created on the
  * first such call; shared by the device's batches, whose chained calls exclude each other anyway): 0.2-0.5 us of host time per
  * launch, no helper threads, 1.5-2 % shorter calls.  Same kernels, same machine code (the gfx950 code object is taken from this
  * library's own fat binary and loaded through the HSA loader), same hand-over protocol, same results; a queue's launches are
  * ordered like a stream's (barrier bit), its first packet acquires at system scope.  Such a call first waits for what the batch's
- * stream still holds and returns with its launches retired, like every chained call.  Shorter calls stay on the streams: a queue that
- * has been idle takes 10 us to start its first wave, as a stream does, and in a 20-launch call the two are level
- * (profiles/r03/direct_dispatch.txt).  If the queues cannot be set up (no HSA agent for the HIP device, no host-visible device
+ * stream still holds and returns with its launches retired, like every chained call.  A queue that has been idle takes 10 us to
+ * start its first wave, as a stream does: in a 20-launch call the two paths are level (one player) or the queues 5-8 % ahead (two
+ * players); calls of a handful of launches stay on the streams (profiles/r03/direct_dispatch.txt).  If the queues cannot be set up (no HSA agent for the HIP device, no host-visible device
  * memory for the kernel arguments, code object not found), the batch keeps launching through its streams.
- * min_launches = 0: never; n > 0: calls of at least n launches; < 0: the default (TETRIS_DIRECT_MIN in the environment, else 128;
+ * min_launches = 0: never; n > 0: calls of at least n launches; < 0: the default (TETRIS_DIRECT_MIN in the environment, else 16;
  * TETRIS_DIRECT=0: batches are created with 0).  Pre-queued calls (TETRIS_PREQUEUE) go through the streams.              */
 int tetris_set_direct_dispatch(tetris_batch *b, int min_launches);
 /* 1 if the batch's last tetris_rollout_launch / tetris_rollout_random went through those queues, 0 if through streams   */

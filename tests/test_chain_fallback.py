@@ -26,13 +26,14 @@ def _check(eng, ref, n, total, steps):
         engines.assert_same_state(eng, ref, idx=idx, where=f"games {lo}..")
 
 
-@pytest.mark.parametrize("P,n", [(1, 65536), (2, 8192)])
-def test_a_late_predecessor_makes_the_call_fall_back_and_the_results_stay_exact(P, n):
+@pytest.mark.parametrize("P,n,direct", [(1, 65536, True), (2, 8192, True), (1, 65536, False), (2, 8192, False)])
+def test_a_late_predecessor_makes_the_call_fall_back_and_the_results_stay_exact(P, n, direct):
     """Chain stream 1 is held by an idle kernel for 30 ms while the bound of a waiting wave is ~1 ms: the launches on the other
     streams give up, the call completes un-chained — OK, every board and the counters equal the oracle, fell-back bit reported."""
     seeds = orc.episode_seed(np.arange(n), 0)
     eng, ref = engines.make("hip", n, P, seeds=seeds), engines.make("oracle", n, P, seeds=seeds)
     assert eng.rollout_is_chained(1)
+    eng.set_direct_dispatch(direct)                        # the library's own queues (calls of >= 16 launches) / the HIP streams
     total = np.zeros(4, np.uint64)
     c, _ = eng.rollout_random(40, 1)                       # chained, undisturbed
     total += c
@@ -40,8 +41,9 @@ def test_a_late_predecessor_makes_the_call_fall_back_and_the_results_stay_exact(
     eng.set_chain_spin_limit(2000)                         # ~1 ms
     before = eng.rollout_totals()                          # (synchronises: nothing may drain the streams between the stall and the launches)
     eng.debug_stall(1, 30000)                              # the second launch of the next call (and every third after it) starts 30 ms late
-    stalled = 50 if P == 2 else 300                        # (300: a call that goes through the library's own queues; 50: through the streams)
+    stalled = 50 if P == 2 else 300                        # (300 on the streams: the call that is enqueued by one host thread per stream)
     eng.rollout_launch(stalled, 1, first_step=40)
+    assert eng.rollout_was_direct() == direct
     total += eng.rollout_totals() - before
     assert eng.take_errors() == FELL_BACK
     assert eng.take_errors() == 0                          # reported once

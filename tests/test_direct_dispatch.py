@@ -28,7 +28,7 @@ def test_direct_dispatch_is_what_runs_and_is_bit_exact(P, n):
     seeds = orc.episode_seed(np.arange(n), 0)
     eng, ref = engines.make("hip", n, P, seeds=seeds), engines.make("oracle", n, P, seeds=seeds)
     assert eng.rollout_is_chained(1)
-    eng.set_direct_dispatch(True, min_launches=1)          # (by default only calls of >= 128 launches go this way)
+    eng.set_direct_dispatch(True, min_launches=1)          # (by default only calls of >= 16 launches go this way)
     total, step = np.zeros(4, np.uint64), 0
     for launches in (1, 2, 3, 7, 20, 117):
         c, ms = eng.rollout_random(launches, 1, first_step=step)
@@ -76,7 +76,7 @@ def test_a_long_call_wraps_the_argument_ring_and_the_flow_control():
     seeds = orc.episode_seed(np.arange(n), 0)
     eng, ref = engines.make("hip", n, 1, seeds=seeds), engines.make("oracle", n, 1, seeds=seeds)
     c, _ = eng.rollout_random(5000, 1)
-    assert eng.rollout_was_direct()                        # the default: calls of >= 128 launches
+    assert eng.rollout_was_direct()                        # the default: calls of >= 16 launches
     _, want = ref.rollout_random(5000, threads=THREADS)
     assert c.tolist() == want.tolist()
     _same(eng, ref, n)
@@ -92,5 +92,5 @@ def test_same_results_with_direct_dispatch_off_and_short_calls_stay_on_the_strea
     assert a.rollout_was_direct() and not b.rollout_was_direct()
     assert ca.tolist() == cb.tolist()
     assert np.array_equal(a.snapshot(), b.snapshot())
-    a.rollout_random(20, 1, first_step=200)
+    a.rollout_random(8, 1, first_step=200)
     assert not a.rollout_was_direct()                      # below the default threshold

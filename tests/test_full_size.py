@@ -201,7 +201,7 @@ def test_long_chained_calls_stay_bit_exact_on_either_launch_path(P, direct):
     step = 0
     for launches in (700, 300, 40):
         c, _ = eng.rollout_random(launches, 1, first_step=step)
-        assert eng.rollout_was_direct() == (direct and launches >= 128)
+        assert eng.rollout_was_direct() == direct
         total += c
         step += launches
     assert eng.take_errors() == 0
