@@ -309,12 +309,12 @@ static inline void write_dispatch(Queues& qs, Pending& pd, int k, const Kernel& 
     __atomic_store_n((uint16_t*)p, header, __ATOMIC_RELEASE);
 }
 // a packet that does nothing but complete `signal` once everything in front of it on queue k has retired
-static inline void write_barrier(Queues& qs, Pending& pd, int k, hsa_signal_t signal) {
+static inline void write_barrier(Queues& qs, Pending& pd, int k, hsa_signal_t signal, int scope = HSA_FENCE_SCOPE_SYSTEM) {
     char* p = claim_packet(qs, pd, k);
     memset(p + 2, 0, 62);
     ((hsa_barrier_and_packet_t*)p)->completion_signal = signal;
     const uint16_t header = (uint16_t)((HSA_PACKET_TYPE_BARRIER_AND << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER) |
-                                       (HSA_FENCE_SCOPE_SYSTEM << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) | (HSA_FENCE_SCOPE_SYSTEM << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE));
+                                       (scope << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) | (scope << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE));
     __atomic_store_n((uint16_t*)p, header, __ATOMIC_RELEASE);
 }
 

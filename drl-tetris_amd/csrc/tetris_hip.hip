@@ -2085,6 +2085,8 @@ static int rollout_direct(tetris_batch* b, aql::Device* dev, int launches, int s
         return ok;
     };
     struct DrainGuard { decltype(drain)& d; bool armed; ~DrainGuard() { if (armed) (void)d(); } } guard{drain, true};
+    // (An empty barrier packet rung in ahead of the first launch, to wake the idle queues while the host prepares, bought nothing:
+    // 5.12-5.38 us per launch with it, 5.15-5.22 without, driver's flags, alternating processes — profiles/r03/direct_dispatch.txt.)
     hsa_signal_t start_sig = qs.first, end_sig = qs.done[(launches - 1) % depth];
     int rc = TETRIS_OK, unflushed = 0;
     for (int l = 0; l < launches; l++) {
