@@ -301,6 +301,8 @@ int tetris_debug_stall(tetris_batch *b, int which, int microseconds, int percent
  *   TETRIS_GATE_GROUP=<n>  launches per run-ahead group (default 120: at most 241 in flight), 8..120
  *   TETRIS_DIRECT=0     batches are created with direct dispatch off; TETRIS_DIRECT_MIN=<n>: its default threshold
  *                       (tetris_set_direct_dispatch)
+ *   TETRIS_DIRECT_UNDER_TOOLS=1  direct dispatch also with a profiling tool library in the process (ROCP_TOOL_LIBRARIES, HSA_TOOLS_LIB or
+ *                       LD_PRELOAD naming rocprof* / roctracer: by default the launches then stay on the streams)
  *   TETRIS_DIRECT_FENCE=none, TETRIS_DIRECT_EDGE=agent|system, TETRIS_DIRECT_PRIO=high  (experiments) direct dispatch: fence scope of
  *                       the packets between a queue's first and last / of its first and last packet; queue priority
  *   TETRIS_TIMING=1     tetris_rollout_launch prints its host-side costs (enqueue per launch, gate waits, until drained) to stderr */
