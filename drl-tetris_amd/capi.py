@@ -59,6 +59,8 @@ _SIGNATURES = {
     "tetris_rollout_is_chained": (C.c_int, [C.c_void_p, C.c_int]),
     "tetris_set_direct_dispatch": (C.c_int, [C.c_void_p, C.c_int]),
     "tetris_rollout_was_direct": (C.c_int, [C.c_void_p]),
+    "tetris_set_xcd_affine": (C.c_int, [C.c_void_p, C.c_int]),
+    "tetris_debug_xcd_skew": (C.c_int, [C.c_void_p, C.c_int]),
     "tetris_debug_code_objects": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_uint64)]),
     "tetris_set_chain_spin_limit": (C.c_int, [C.c_void_p, C.c_uint32]),
     "tetris_debug_stall": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
@@ -392,6 +394,20 @@ class TetrisBatch:
         if rc < 0:
             self._check(rc)
         return bool(rc)
+
+    def rollout_was_affine(self):
+        """The last rollout call ran the XCD-affine chained kernel (include/tetris_hip.h: tetris_set_xcd_affine)."""
+        rc = self.lib.tetris_rollout_was_direct(self._h)
+        if rc < 0:
+            self._check(rc)
+        return rc == 2
+
+    def set_xcd_affine(self, on):
+        self._check(self.lib.tetris_set_xcd_affine(self._h, 1 if on else 0))
+
+    def debug_xcd_skew(self, skew):
+        """Test aid: the kernels are told start XCDs that are off by `skew` (every workgroup then finds itself misplaced)."""
+        self._check(self.lib.tetris_debug_xcd_skew(self._h, int(skew)))
 
     def set_chain_spin_limit(self, polls):
         """Polls of the predecessor's epoch word after which a waiting wave of a chained launch gives up (0 = default, ~2 s)."""

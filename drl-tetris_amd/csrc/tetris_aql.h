@@ -47,6 +47,10 @@ struct Queues {                        // one set per device: chained calls of a
     hsa_signal_t done[CHAIN_STREAMS] = {};       // last packet of a call on queue k
     hsa_signal_t first{};                        // first packet of a call (its start time)
     bool ok = false;
+    // XCD-affine launches (k_chain_affine): the XCD block 0 of a launch on queue k lands on, measured when the queues are made
+    // (blocks are dealt round-robin over the eight XCDs from there); affine_ok: every queue showed that pattern, twice
+    uint32_t xcd_base[CHAIN_STREAMS] = {};
+    bool affine_ok = false, calibrated = false;
 };
 struct Device {                        // one per HIP device of the process, made on first use, never torn down
     int hip_device = -1;
@@ -55,13 +59,16 @@ struct Device {                        // one per HIP device of the process, mad
     hsa_amd_memory_pool_t dev_pool{};
     uint64_t ts_freq = 0;
     std::vector<hsa_executable_t> exes;
-    Kernel chain1, duo, blocker;
+    Kernel chain1, chain1_affine, duo, blocker, xcc_probe;
     std::vector<std::vector<char>> images;   // the code objects' bytes: the loader (and a profiler's code-object tracking) keep reading them
     Queues qs;
     std::string why;                   // why it is not ok
 };
 
-constexpr int SLOTS = 512;             // kernel-argument slots per queue (> 2 * wgroup + 1)
+#ifndef TE_AQL_SLOTS
+#define TE_AQL_SLOTS 4096
+#endif
+constexpr int SLOTS = TE_AQL_SLOTS;    // kernel-argument slots per queue (> 2 * wgroup + 1)
 constexpr uint32_t QUEUE_PACKETS = 1024;
 
 static std::mutex g_mutex;
@@ -107,6 +114,8 @@ static hsa_status_t on_symbol(hsa_executable_t, hsa_agent_t, hsa_executable_symb
     if (name.rfind("_Z7k_chainILi1EEvN2te5KArgsE", 0) == 0) k = &d->chain1;
     else if (name.rfind("_Z5k_duoILi6ELb1ELb0EEvN2te5KArgsE", 0) == 0) k = &d->duo;
     else if (name.rfind("_Z9k_blockerPKjy", 0) == 0) k = &d->blocker;            // (test aid: tetris_debug_stall)
+    else if (name.rfind("_Z14k_chain_affineILi1EEvN2te5KArgsE", 0) == 0) k = &d->chain1_affine;
+    else if (name.rfind("tetris_k_xcc_probe", 0) == 0) k = &d->xcc_probe;
     if (!k) return HSA_STATUS_SUCCESS;
     bool ok = hsa_executable_symbol_get_info(s, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_OBJECT, &k->object) == HSA_STATUS_SUCCESS;
     ok = ok && hsa_executable_symbol_get_info(s, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_KERNARG_SEGMENT_SIZE, &k->kernarg) == HSA_STATUS_SUCCESS;
@@ -216,7 +225,7 @@ static void destroy_queues(Queues& qs) {
     }
     if (qs.first.handle) (void)hsa_signal_destroy(qs.first);
     for (int k = 0; k < CHAIN_STREAMS; k++) { qs.q[k] = nullptr; qs.kernarg[k] = nullptr; qs.done[k] = hsa_signal_t{}; qs.gate[k][0] = qs.gate[k][1] = hsa_signal_t{}; }
-    qs.first = hsa_signal_t{}; qs.ok = false;
+    qs.first = hsa_signal_t{}; qs.ok = false; qs.affine_ok = false; qs.calibrated = false;
 }
 
 static bool make_queues(Device* d, std::string& why) {
@@ -316,6 +325,46 @@ static inline void write_barrier(Queues& qs, Pending& pd, int k, hsa_signal_t si
     const uint16_t header = (uint16_t)((HSA_PACKET_TYPE_BARRIER_AND << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER) |
                                        (scope << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) | (scope << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE));
     __atomic_store_n((uint16_t*)p, header, __ATOMIC_RELEASE);
+}
+
+// Where do a queue's workgroups land?  1024 workgroups (the grid of a 64k-board launch) on every queue, twice: XCD-affine launches are
+// enabled only if every launch dealt its blocks round-robin over the eight XCDs — block b on XCD (x0 + b) mod 8 — from the same
+// start x0 both times (k_chain_affine checks the same thing again, per workgroup, in every launch).
+static void calibrate_affine(Device* d) {
+    std::lock_guard<std::mutex> lock(g_mutex);
+    Queues& qs = d->qs;
+    if (!qs.ok || qs.calibrated) return;
+    qs.calibrated = true;
+    { const char* e = getenv("TETRIS_AFFINE"); if (e && e[0] == '0') return; }
+    if (!d->xcc_probe.ok || !d->chain1_affine.ok || d->xcc_probe.priv || d->chain1_affine.priv) return;
+    constexpr uint32_t BLOCKS = 1024;
+    const size_t words = (size_t)2 * CHAIN_STREAMS * BLOCKS;
+    uint32_t* out = nullptr;
+    if (hsa_amd_memory_pool_allocate(d->dev_pool, words * 4, 0, (void**)&out) != HSA_STATUS_SUCCESS) return;
+    std::vector<uint32_t> host(words, 0xFFu);
+    bool ok = hsa_memory_copy(out, host.data(), words * 4) == HSA_STATUS_SUCCESS;
+    for (int rep = 0; rep < 2 && ok; rep++) {
+        Pending pd;
+        for (int k = 0; k < CHAIN_STREAMS; k++) {
+            struct { uint32_t* out; } args = {out + ((size_t)rep * CHAIN_STREAMS + k) * BLOCKS};
+            hsa_signal_store_relaxed(qs.done[k], 1);
+            write_dispatch(qs, pd, k, d->xcc_probe, &args, sizeof args, BLOCKS, HSA_FENCE_SCOPE_SYSTEM, HSA_FENCE_SCOPE_SYSTEM, qs.done[k]);
+        }
+        ring(qs, pd);
+        for (int k = 0; k < CHAIN_STREAMS; k++) ok = wait_signal(qs.done[k]) && ok;
+    }
+    ok = ok && hsa_memory_copy(host.data(), out, words * 4) == HSA_STATUS_SUCCESS;
+    (void)hsa_amd_memory_pool_free(out);
+    if (!ok) return;
+    for (int k = 0; k < CHAIN_STREAMS; k++) {
+        const uint32_t* a = &host[(size_t)k * BLOCKS];
+        const uint32_t* b = &host[((size_t)CHAIN_STREAMS + k) * BLOCKS];
+        if (a[0] > 7u || a[0] != b[0]) return;
+        for (uint32_t i = 0; i < BLOCKS; i++)
+            if (a[i] != ((a[0] + i) & 7u) || b[i] != a[i]) return;
+        qs.xcd_base[k] = a[0];
+    }
+    qs.affine_ok = true;
 }
 
 // waits until queue k has retired everything it was given (before the queues go away; after a test's idle kernel)

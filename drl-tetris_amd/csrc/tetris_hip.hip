@@ -47,24 +47,37 @@ constexpr int CHAIN_LANES = TE_CHAIN_LANES;
                                    // (with the epoch words still packed 32 to a line it had been 4.9-5.06 against 4.71-4.80)
 #endif
 constexpr int CHAIN_STREAMS = TE_CHAIN_STREAMS;
-template <int P>
-__global__ __launch_bounds__(64) void k_chain(KArgs a) {
+// XCD-AFFINE form (k_chain_affine; direct dispatch only, tetris_aql.h).  The write-through hand-off above crosses the fabric twice per
+// step because block b of consecutive launches never meets its own XCD again (a queue deals its blocks round-robin over the eight XCDs
+// from a start of its own: profiles/r03/handoff_experiments.txt).  Here the GAMES follow the XCD instead: the workgroup that finds
+// itself on XCD x takes the game block (b & ~7) | x, so a block is stepped on the same XCD in every launch and its state and epoch
+// word can stay in that XCD's L2 — plain stores, `sc1` loads (past the CU's L1, served by the L2).  One L2 is coherent for all CUs
+// of its XCD; nothing else is relied on.  That the eight workgroups of a group of eight really sit on eight different XCDs is
+// CHECKED, by every workgroup for itself: the queue's start XCD is measured when the queue is made (a.xcd_base), and a
+// workgroup that is not on XCD (xcd_base + b) mod 8 touches nothing, raises F_PLACE and leaves — its games then look abandoned to the
+// next launch, whose waves give up, and the host finishes the call un-chained (chain_recover) and switches the affine form off.
+// What makes this FASTER only with direct dispatch: the packets between a queue's first and last carry no cache maintenance
+// (a kernel boundary's L2 write-back + invalidate, three times per 12 us, cost more than the fabric: +0.1 us per launch through
+// streams); the queue's last packet releases, so memory is current when the call returns.
+template <int P, bool AFFINE>
+__device__ __forceinline__ void chain_body(const KArgs& a) {
     __shared__ __attribute__((aligned(16))) uint32_t s_shapes[SHAPE_WORDS];
     const int lane = threadIdx.x;
     if (a.steps < 0) { chain_census(a, lane == 0); return; }
-#if defined(TE_EXPERIMENT_AFFINE)
-    // experiment (profiles/r03/handoff_experiments.txt): the games of a block follow the workgroup's XCD — block (b & ~7) | XCC_ID — so
-    // that a game is stepped on the same XCD in every launch and its state can stay in that XCD's L2 (plain stores).  Blocks are
-    // dealt round-robin over the XCDs from a start that differs per stream, so the map is a bijection; NOTHING here verifies that.
-    // Bit-exact in a 2000-launch soak and 0.1 us per launch SLOWER than the write-through hand-off: not the product path.
-    uint32_t xcc_;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_));
-    const int wave = (int)((blockIdx.x & ~7u) | (xcc_ & 7u));
-    constexpr int CMEM = MEM_AFFINE;
-#else
-    const int wave = blockIdx.x;
-    constexpr int CMEM = MEM_AGENT;
-#endif
+    constexpr int CMEM = AFFINE ? MEM_AFFINE : MEM_AGENT;
+    int wave = blockIdx.x;
+    if (AFFINE) {
+        uint32_t xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        xcc &= 0xFu;
+        if (blockIdx.x == 0 && lane == 0) ((volatile uint32_t*)a.status)[F_XCC0 + (a.xcd_slot & 3u)] = 0x100u | xcc;      // where this queue starts dealing: the host's expectation for the next call
+        if (xcc != ((a.xcd_base + blockIdx.x) & 7u)) {          // not where the host expects this block to run: hands off
+            if (lane == 0) ((volatile uint32_t*)a.status)[F_PLACE] = 1u;
+            return;
+        }
+        wave = (int)((blockIdx.x & ~7u) | xcc);
+        if (wave * CHAIN_LANES >= a.n) return;                  // (padding of the last group of eight: no games, no epoch word)
+    }
     const int i = wave * CHAIN_LANES + lane;
     const bool active = lane < CHAIN_LANES && i < a.n;
     LaneCounters cnt = {0, 0, 0, 0};
@@ -92,12 +105,24 @@ __global__ __launch_bounds__(64) void k_chain(KArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every store (and counter atomic) of this wave has been acknowledged
 #endif
     TE_STAMP_CHAIN(a.epoch, 5);
-#if defined(TE_EXPERIMENT_AFFINE)
-    if (lane == 0) *(volatile uint32_t*)(a.chain + (size_t)wave * CHAIN_STRIDE) = a.epoch;
-#else
-    if (lane == 0) st_agent(a.chain + (size_t)wave * CHAIN_STRIDE, a.epoch);
-#endif
+    if (lane == 0) {
+        if (AFFINE) *(volatile uint32_t*)(a.chain + (size_t)wave * CHAIN_STRIDE) = a.epoch;       // stays in this XCD's L2, where the next launch's wave polls it
+        else st_agent(a.chain + (size_t)wave * CHAIN_STRIDE, a.epoch);
+    }
     TE_STAMP_CHAIN(a.epoch, 6);
+}
+template <int P>
+__global__ __launch_bounds__(64) void k_chain(KArgs a) { chain_body<P, false>(a); }
+template <int P>
+__global__ __launch_bounds__(64) void k_chain_affine(KArgs a) { chain_body<P, true>(a); }
+template __global__ void k_chain_affine<1>(KArgs);
+// the XCD every workgroup of a launch lands on (calibration of the affine form: aql::make_queues)
+extern "C" __global__ void tetris_k_xcc_probe(uint32_t* out) {
+    if (threadIdx.x == 0) {
+        uint32_t xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        out[blockIdx.x] = xcc & 0xFu;
+    }
 }
 
 // Measurement / test aid: keeps a stream busy until the HOST sets `*go` (a word in pinned host memory; NULL: no such word) or
@@ -835,6 +860,10 @@ struct tetris_batch {
     int direct_min = 16;                 // calls of at least this many launches go through the device's own queues; 0: never (TETRIS_DIRECT=0 / TETRIS_DIRECT_MIN, tetris_set_direct_dispatch)
     bool last_direct = false;            // the last rollout call went through those queues
     bool direct_used = false;            // ... and so did some call of this batch (its destruction waits for the queues)
+    int use_affine = 1;                  // XCD-affine launches (k_chain_affine) where the device's queues allow them; TETRIS_AFFINE=0 / tetris_set_xcd_affine
+    bool last_affine = false;            // the last rollout call ran them
+    uint32_t xcd_skew = 0;               // test aid (tetris_debug_xcd_skew): added to the queues' measured start XCDs
+    int affine_failures = 0;             // calls in which a workgroup found itself misplaced (three: the affine form is switched off)
     bool home_async = false;             // asynchronous (_dev) work was enqueued on the batch's stream since the last drain
     bool busy = true;                    // something was enqueued on one of the batch's streams since the last drain
     // Run-ahead gate of the asynchronous entry points: every GATE_GROUP launches an event is recorded; before a new group is
@@ -1029,6 +1058,20 @@ static int finish_call(tetris_batch* b, bool drained = false) {
     volatile uint32_t* f = b->flags;
     // (F_EXHAUSTED / F_FIFO: capacity errors are confined to the games they happened in — tetris_take_errors)
     int rc = TETRIS_OK;
+    // a workgroup of an affine launch was not where its queue's calibration put it (it left its games alone): that form stays off,
+    // and the games it — and whoever waited for it — left behind are finished like abandoned ones
+    const bool misplaced = f[F_PLACE] != 0;
+    if (misplaced) {
+        // The games such workgroups — and whoever waited for them — left behind are finished like abandoned ones.  A queue's start XCD
+        // moves when the driver re-maps hardware queues (many queues in the process); the next call expects what this one saw.
+        // Not the caller's business unless it keeps happening: chaining stays as it was, the affine form goes after three such calls.
+        const int keep_chain = b->use_chain;
+        const bool keep_fell_back = b->chain_fell_back;
+        f[F_PLACE] = 0;
+        if ((rc = chain_recover(b))) return rc;
+        b->use_chain = keep_chain; b->chain_fell_back = keep_fell_back;
+        if (++b->affine_failures >= 3) b->use_affine = 0;
+    }
     if (f[F_CHAIN] && (rc = chain_recover(b))) return rc;       // waves of a chained launch gave up: their games are finished un-chained
     if ((rc = service_flags(b))) return rc;                     // before the argument error below: an extend request is never dropped
     if (f[F_BADARG]) {
@@ -1190,6 +1233,7 @@ static int create_impl(tetris_batch** out, int n_games, int n_players, int heigh
     { const char* e = getenv("TETRIS_NO_DUO"); b->use_duo = !(e && e[0] == '1'); }
     { const char* e = getenv("TETRIS_NO_CHAIN"); b->use_chain = !(e && e[0] == '1'); }
     b->direct_min = default_direct_min();
+    { const char* e = getenv("TETRIS_AFFINE"); b->use_affine = !(e && e[0] == '0'); }
     { const char* e = getenv("TETRIS_GRAPH"); b->use_graph = (e && e[0] == '1'); }
     { const char* e = getenv("TETRIS_CHAIN_SPIN_LIMIT"); if (e && atoll(e) > 0) b->chain_spin_limit = (uint32_t)atoll(e); }
     b->nw = b->tint ? NWORDS_TINT : NWORDS;
@@ -1272,6 +1316,22 @@ int tetris_set_direct_dispatch(tetris_batch* b, int min_launches) {
     return TETRIS_OK;
 }
 
+int tetris_set_xcd_affine(tetris_batch* b, int on) {
+    int rc = check_batch(b);
+    if (rc) return rc;
+    if ((rc = finish_call(b))) return rc;
+    b->use_affine = on ? 1 : 0;
+    return TETRIS_OK;
+}
+
+int tetris_debug_xcd_skew(tetris_batch* b, int skew) {
+    int rc = check_batch(b);
+    if (rc) return rc;
+    if ((rc = finish_call(b))) return rc;
+    b->xcd_skew = (uint32_t)skew & 7u;
+    return TETRIS_OK;
+}
+
 int tetris_debug_code_objects(int* count, uint64_t* bytes) {
     if (!count || !bytes) return fail(TETRIS_E_ARG, "count / bytes is NULL");
     std::vector<std::vector<char>> images;
@@ -1286,7 +1346,7 @@ int tetris_debug_code_objects(int* count, uint64_t* bytes) {
 int tetris_rollout_was_direct(tetris_batch* b) {
     int rc = check_batch(b, false);
     if (rc) return rc;
-    return b->last_direct ? 1 : 0;
+    return b->last_direct ? (b->last_affine ? 2 : 1) : 0;
 }
 
 int tetris_set_chain_spin_limit(tetris_batch* b, uint32_t polls) {
@@ -2054,8 +2114,13 @@ static int rollout_direct(tetris_batch* b, aql::Device* dev, int launches, int s
                           int ms, int group, float* elapsed_ms) {
     aql::Queues& qs = dev->qs;
     const int depth = b->chain_depth;
-    const aql::Kernel& kern = b->P == 1 ? dev->chain1 : dev->duo;
-    const uint32_t blocks = b->P == 1 ? (uint32_t)((b->N + CHAIN_LANES - 1) / CHAIN_LANES) : (uint32_t)((b->N + 31) / 32);
+    // one-player batches on queues that deal their blocks round-robin over the XCDs: the XCD-affine kernel (k_chain_affine), whole groups
+    // of eight workgroups, no cache maintenance between a queue's launches
+    const bool affine = b->P == 1 && b->use_affine && qs.affine_ok && dev->chain1_affine.ok && CHAIN_LANES == 64;
+    b->last_affine = affine;
+    const aql::Kernel& kern = affine ? dev->chain1_affine : (b->P == 1 ? dev->chain1 : dev->duo);
+    uint32_t blocks = b->P == 1 ? (uint32_t)((b->N + CHAIN_LANES - 1) / CHAIN_LANES) : (uint32_t)((b->N + 31) / 32);
+    if (affine) blocks = (blocks + 7u) & ~7u;
     const int wgroup = std::min(aql::SLOTS / 2 - 2, std::max(8, group / depth));
     static const bool timing = getenv("TETRIS_TIMING") != nullptr;
     // (experiment knob: the packets between a queue's first and last with fence scope "none" instead of "agent")
@@ -2113,8 +2178,14 @@ static int rollout_direct(tetris_batch* b, aql::Device* dev, int launches, int s
         // through (sc1), the counters are atomics performed at the memory side, the flag words live in host memory — and the
         // host waits for the completion signals.  (TETRIS_DIRECT_EDGE=system / agent: both edges at that scope, experiment knob.)
         static const int edge_knob = [] { const char* e = getenv("TETRIS_DIRECT_EDGE"); return !e ? -1 : (!strcmp(e, "agent") ? HSA_FENCE_SCOPE_AGENT : HSA_FENCE_SCOPE_SYSTEM); }();
-        const int acq_edge = edge_knob < 0 ? HSA_FENCE_SCOPE_SYSTEM : edge_knob, rel_edge = edge_knob < 0 ? HSA_FENCE_SCOPE_AGENT : edge_knob;
-        aql::write_dispatch(qs, pd, k, kern, &a, sizeof a, blocks, first_on_queue ? acq_edge : mid_scope, last_on_queue ? rel_edge : mid_scope, sig);
+        // The affine kernel keeps its state in the XCDs' L2s: its queue's LAST packet releases at system scope (memory is current when the
+        // call returns), and between first and last there is NO cache maintenance at all — except that a packet which re-uses the first
+        // slot of the argument ring acquires at agent scope (the scalar caches may still hold what the slot held 4096 launches ago).
+        const int acq_edge = edge_knob < 0 ? HSA_FENCE_SCOPE_SYSTEM : edge_knob, rel_edge = edge_knob < 0 ? (affine ? HSA_FENCE_SCOPE_SYSTEM : HSA_FENCE_SCOPE_AGENT) : edge_knob;
+        const bool ring_wraps = qs.issued[k].load() % aql::SLOTS == 0;
+        const int mid = affine ? HSA_FENCE_SCOPE_NONE : mid_scope;
+        a.xcd_base = qs.xcd_base[k] + b->xcd_skew; a.xcd_slot = (uint32_t)k;
+        aql::write_dispatch(qs, pd, k, kern, &a, sizeof a, blocks, first_on_queue ? acq_edge : (ring_wraps ? HSA_FENCE_SCOPE_AGENT : mid), last_on_queue ? rel_edge : mid, sig);
         // the first launches go out one by one (the GPU is idle), later ones eight at a time (one fence + read back per eight)
         if (++unflushed >= 8 || l < 2 * depth || l == launches - 1) { aql::ring(qs, pd); unflushed = 0; }
     }
@@ -2133,7 +2204,14 @@ static int rollout_direct(tetris_batch* b, aql::Device* dev, int launches, int s
             hsa_amd_profiling_get_dispatch_time(dev->gpu, end_sig, &t1) == HSA_STATUS_SUCCESS && t1.end >= t0.start)
             ms_events = (float)((double)(t1.end - t0.start) * 1e3 / (double)dev->ts_freq);
     }
+    if (affine)                                 // where the queues dealt from in this call (block 0 of every launch says): what the next call expects
+        for (int k = 0; k < depth; k++) {
+            const uint32_t seen = ((volatile uint32_t*)b->flags)[F_XCC0 + k];
+            if (seen & 0x100u) { qs.xcd_base[k] = seen & 7u; ((volatile uint32_t*)b->flags)[F_XCC0 + k] = 0; }
+        }
+    const bool was_misplaced = ((volatile uint32_t*)b->flags)[F_PLACE] != 0;
     if ((rc = finish_call(b, true))) return rc;
+    if (affine && !was_misplaced) b->affine_failures = 0;
     if (elapsed_ms) *elapsed_ms = ms_events;
     if (timing) {
         const double enq = std::chrono::duration<double>(t_enq - t_begin).count();
@@ -2246,7 +2324,7 @@ int tetris_rollout_launch(tetris_batch* b, int launches, int steps_per_launch, u
         for (int k = 0; k < CHAIN_STREAMS; k++) HIP_TRY(hipStreamWaitEvent(b->chain_stream[k], b->chain_ev[CHAIN_STREAMS], 0));
         group = 1 << 20;
     }
-    b->last_direct = false;
+    b->last_direct = false; b->last_affine = false;
     if (chained && !prequeue && b->direct_min > 0) {
         // the device's own queues (tetris_aql.h); anything that keeps them from being set up switches them off for this batch.  They
         // are made by the first chained call of ANY length (loading the code object takes ~15 ms: a warm-up call's business,
@@ -2257,6 +2335,7 @@ int tetris_rollout_launch(tetris_batch* b, int launches, int steps_per_launch, u
             b->direct_min = 0;
             if (getenv("TETRIS_TIMING")) fprintf(stderr, "[tetris] direct dispatch is off: %s\n", why.c_str());
         } else if (launches >= b->direct_min) {
+            aql::calibrate_affine(dev);
             if (b->home_async) { HIP_TRY(hipStreamSynchronize(home)); }      // what the batch's stream still holds comes first
             b->last_direct = true; b->direct_used = true;
             if (getenv("TETRIS_TIMING")) fprintf(stderr, "[tetris timing] call entry -> direct dispatch %.1f us\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_entry).count() * 1e6);

@@ -45,6 +45,8 @@ struct KArgs {
     uint32_t* chain;          // chained launches: one epoch word per wave (NULL = launches are ordered by the stream)
     uint32_t epoch;           // chained launches: this launch's number; its waves wait for epoch - 1 and publish epoch
     uint32_t chain_spin_limit; // chained launches: polls of the epoch word before a wave gives up (tetris_set_chain_spin_limit)
+    uint32_t xcd_base;        // XCD-affine chained launches (k_chain_affine): the XCD block 0 of this launch's queue is expected on
+    uint32_t xcd_slot;        // ... and the number of that queue (block 0 reports where it really is: F_XCC0 + xcd_slot)
     uint32_t* shadow;         // split mode, side 1: undo record of the speculative loop-1 pass, UNDO_WORDS + nw rows of n_stride words
     int split_side;           // split mode: the player index this batch holds
     const uint32_t* xw[4];    // split mode: exchange words [n] each: my A, the opponent's A, player 0's B, player 1's B (separate buffers:
@@ -132,6 +134,9 @@ TE_HD bool chain_wait(const KArgs& a, uint32_t wave, bool marker) {
         const uint32_t v = ld_agent(word);
         if (v == want) return true;
         if (v & CHAIN_ABANDONED) return false;              // an earlier launch's wave gave up: nothing to add
+        // an XCD-affine launch found workgroups misplaced (they touched nothing; their games' epochs will never come): every waiting
+        // wave learns it from the flag word within ~0.1 ms instead of waiting out its bound
+        if ((spin & 255u) == 255u && ((volatile uint32_t*)a.status)[F_PLACE]) break;
 #if defined(__HIP_DEVICE_COMPILE__)
         __builtin_amdgcn_s_sleep(TE_CHAIN_SLEEP);
 #endif

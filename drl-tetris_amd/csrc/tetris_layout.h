@@ -79,7 +79,9 @@ enum Flag : int {
     F_BADARG = 3,      // != 0: an output capacity was exceeded (get_actions)
     F_CHAIN = 4,       // != 0: a wave of a chained launch gave up waiting for its predecessor (the host finishes its games un-chained)
     F_GO = 5,          // written by the HOST: releases the blocker kernel of a pre-queued rollout (TETRIS_PREQUEUE)
-    NFLAGS = 8
+    F_PLACE = 6,       // != 0: a workgroup of an XCD-affine chained launch found itself on another XCD than the host expected for its queue
+    F_XCC0 = 8,        // [3] 0x100 | the XCD that block 0 of the last affine launch on queue k landed on (the host's expectation for the next call)
+    NFLAGS = 16
 };
 
 // ---------------------------------------------------------------- addressing

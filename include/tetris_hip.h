@@ -266,8 +266,25 @@ int tetris_set_chained(tetris_batch *b, int on);
  * min_launches = 0: never; n > 0: calls of at least n launches; < 0: the default (TETRIS_DIRECT_MIN in the environment, else 16;
  * TETRIS_DIRECT=0: batches are created with 0).  Pre-queued calls (TETRIS_PREQUEUE) go through the streams.              */
 int tetris_set_direct_dispatch(tetris_batch *b, int min_launches);
-/* 1 if the batch's last tetris_rollout_launch / tetris_rollout_random went through those queues, 0 if through streams   */
+/* 0 if the batch's last tetris_rollout_launch / tetris_rollout_random went through streams, 1 if through those queues, 2 if through
+ * them with the XCD-affine kernel (below)                                                                                */
 int tetris_rollout_was_direct(tetris_batch *b);
+/* XCD-AFFINE chained launches (default on; one-player batches, direct dispatch only).  The MI355X has eight XCDs, each with an L2 of
+ * its own that is coherent for its own CUs only; a queue deals a launch's workgroups round-robin over the XCDs, from a start of
+ * its own.  With the plain hand-over a game's state therefore crosses the fabric twice per step (written through by one XCD, read
+ * by another).  In the affine form the workgroup that finds itself on XCD x (hardware register XCC_ID) takes the game block
+ * (b & ~7) | x: a game is stepped on the same XCD in every launch, its state and epoch word stay in that XCD's L2 (plain stores,
+ * L1-bypassing loads), and the packets between a queue's first and last carry no cache maintenance; the last one releases at
+ * system scope, so memory is current when the call returns.  3.5-3.6 us per launch instead of 4.0 at 64k boards, same results.
+ * Relied on: one XCD's L2 is coherent for that XCD's CUs.  Checked, not relied on: that the eight workgroups of a group of eight
+ * sit on eight different XCDs — the queues' start XCDs are measured when the queues are made, the form is used only if every
+ * queue dealt 1024 workgroups round-robin twice, and in every launch every workgroup compares its XCC_ID with what that
+ * measurement predicts; one that is elsewhere touches nothing, its games look abandoned to the next launch, and the call ends
+ * like any chained call whose waves gave up (finished un-chained, exact, TETRIS_ERR_CHAIN_FELL_BACK) with this form off for
+ * the batch from then on.  on = 0: the plain hand-over.  TETRIS_AFFINE=0 in the environment: batches are created with it off. */
+int tetris_set_xcd_affine(tetris_batch *b, int on);
+/* TEST AID for the check above: `skew` (0..7) is added to the start XCDs the kernels are told                              */
+int tetris_debug_xcd_skew(tetris_batch *b, int skew);
 /* TEST AID (needs no GPU): the gfx950 code objects direct dispatch would load — found in this library's own fat binary —: their
  * number and total size in bytes.  0 objects = direct dispatch cannot work with this build (e.g. a compressed offload bundle).  */
 int tetris_debug_code_objects(int *count, uint64_t *bytes);
@@ -301,6 +318,7 @@ int tetris_debug_stall(tetris_batch *b, int which, int microseconds, int percent
  *   TETRIS_GATE_GROUP=<n>  launches per run-ahead group (default 120: at most 241 in flight), 8..120
  *   TETRIS_DIRECT=0     batches are created with direct dispatch off; TETRIS_DIRECT_MIN=<n>: its default threshold
  *                       (tetris_set_direct_dispatch)
+ *   TETRIS_AFFINE=0     no XCD-affine launches (tetris_set_xcd_affine)
  *   TETRIS_DIRECT_UNDER_TOOLS=1  direct dispatch also with a profiling tool library in the process (ROCP_TOOL_LIBRARIES, HSA_TOOLS_LIB or
  *                       LD_PRELOAD naming rocprof* / roctracer: by default the launches then stay on the streams)
  *   TETRIS_DIRECT_FENCE=none, TETRIS_DIRECT_EDGE=agent|system, TETRIS_DIRECT_PRIO=high  (experiments) direct dispatch: fence scope of

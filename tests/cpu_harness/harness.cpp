@@ -252,6 +252,8 @@ int tetris_set_chained(tetris_batch*, int) { return TETRIS_OK; }
 int tetris_set_chain_spin_limit(tetris_batch*, uint32_t) { return TETRIS_OK; }
 int tetris_set_direct_dispatch(tetris_batch*, int) { return TETRIS_OK; }
 int tetris_rollout_was_direct(tetris_batch*) { return 0; }
+int tetris_set_xcd_affine(tetris_batch*, int) { return TETRIS_OK; }
+int tetris_debug_xcd_skew(tetris_batch*, int) { return TETRIS_OK; }
 int tetris_debug_code_objects(int* count, uint64_t* bytes) { if (count) *count = 0; if (bytes) *bytes = 0; return TETRIS_OK; }
 int tetris_debug_stall(tetris_batch*, int, int, int) { return TETRIS_OK; }
 int tetris_debug_clock_khz(tetris_batch*, int* khz) { if (khz) *khz = 0; return TETRIS_OK; }

@@ -21,7 +21,7 @@ def _same(eng, ref, n, where=""):
         engines.assert_same_state(eng, ref, idx=idx, where=f"{where} games {lo}..")
 
 
-@pytest.mark.parametrize("P,n", [(1, 65536), (2, 65536), (1, 1000), (2, 33)])
+@pytest.mark.parametrize("P,n", [(1, 65536), (2, 65536), (1, 1000), (1, 70), (2, 33)])
 def test_direct_dispatch_is_what_runs_and_is_bit_exact(P, n):
     """Chained calls go through the library's own queues (asserted, not assumed); 150 launches in calls of 1, 2, 3, 7, 20
     and 117 launches (fewer launches than queues; a call's first and last packet on the same queue) against the oracle."""
@@ -33,6 +33,7 @@ def test_direct_dispatch_is_what_runs_and_is_bit_exact(P, n):
     for launches in (1, 2, 3, 7, 20, 117):
         c, ms = eng.rollout_random(launches, 1, first_step=step)
         assert eng.rollout_was_direct()
+        assert eng.rollout_was_affine() == (P == 1)          # one-player batches: the XCD-affine kernel (tetris_set_xcd_affine)
         assert ms > 0.0
         total += c
         step += launches
@@ -94,3 +95,37 @@ def test_same_results_with_direct_dispatch_off_and_short_calls_stay_on_the_strea
     assert np.array_equal(a.snapshot(), b.snapshot())
     a.rollout_random(8, 1, first_step=200)
     assert not a.rollout_was_direct()                      # below the default threshold
+
+
+def test_xcd_affine_launches_equal_the_plain_hand_over_and_misplaced_launches_cost_time_not_results():
+    """The XCD-affine chained kernel (include/tetris_hip.h: tetris_set_xcd_affine) against the write-through one on the same games;
+    then the kernels are told start XCDs that are off by three: every workgroup finds itself misplaced and touches nothing, the call
+    is finished un-chained — exact, and not the caller's business: no error bit, chaining stays on — and after three such calls
+    the affine form is off for the batch."""
+    n = 65536
+    seeds = orc.episode_seed(np.arange(n), 0)
+    a, b = engines.make("hip", n, 1, seeds=seeds), engines.make("hip", n, 1, seeds=seeds)
+    ref = engines.make("oracle", n, 1, seeds=seeds)
+    b.set_xcd_affine(False)
+    total = np.zeros(4, np.uint64)
+    ca, _ = a.rollout_random(400, 1)
+    cb, _ = b.rollout_random(400, 1)
+    assert a.rollout_was_affine() and b.rollout_was_direct() and not b.rollout_was_affine()
+    assert ca.tolist() == cb.tolist()
+    assert np.array_equal(a.snapshot(), b.snapshot())
+    total += ca
+    a.debug_xcd_skew(3)
+    step = 400
+    for rep in range(3):
+        c, _ = a.rollout_random(20, 1, first_step=step)
+        assert a.rollout_was_affine()                                  # tried, every workgroup stood aside, finished un-chained
+        assert a.take_errors() == 0 and a.rollout_is_chained(1)
+        total += c
+        step += 20
+    a.debug_xcd_skew(0)
+    c, _ = a.rollout_random(40, 1, first_step=step)
+    assert a.rollout_was_direct() and not a.rollout_was_affine()      # three strikes: the affine form is off
+    total += c
+    _, want = ref.rollout_random(500, threads=THREADS)
+    assert total.tolist() == want.tolist()
+    _same(a, ref, n)
