@@ -59,7 +59,7 @@ struct Device {                        // one per HIP device of the process, mad
     hsa_amd_memory_pool_t dev_pool{};
     uint64_t ts_freq = 0;
     std::vector<hsa_executable_t> exes;
-    Kernel chain1, chain1_affine, duo, blocker, xcc_probe;
+    Kernel chain1, chain1_affine, duo, duo_affine, blocker, xcc_probe;
     std::vector<std::vector<char>> images;   // the code objects' bytes: the loader (and a profiler's code-object tracking) keep reading them
     Queues qs;
     std::string why;                   // why it is not ok
@@ -116,6 +116,7 @@ static hsa_status_t on_symbol(hsa_executable_t, hsa_agent_t, hsa_executable_symb
     else if (name.rfind("_Z9k_blockerPKjy", 0) == 0) k = &d->blocker;            // (test aid: tetris_debug_stall)
     else if (name.rfind("_Z14k_chain_affineILi1EEvN2te5KArgsE", 0) == 0) k = &d->chain1_affine;
     else if (name.rfind("tetris_k_xcc_probe", 0) == 0) k = &d->xcc_probe;
+    else if (name.rfind("_Z12k_duo_affineN2te5KArgsE", 0) == 0) k = &d->duo_affine;
     if (!k) return HSA_STATUS_SUCCESS;
     bool ok = hsa_executable_symbol_get_info(s, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_OBJECT, &k->object) == HSA_STATUS_SUCCESS;
     ok = ok && hsa_executable_symbol_get_info(s, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_KERNARG_SEGMENT_SIZE, &k->kernarg) == HSA_STATUS_SUCCESS;
@@ -336,7 +337,7 @@ static void calibrate_affine(Device* d) {
     if (!qs.ok || qs.calibrated) return;
     qs.calibrated = true;
     { const char* e = getenv("TETRIS_AFFINE"); if (e && e[0] == '0') return; }
-    if (!d->xcc_probe.ok || !d->chain1_affine.ok || d->xcc_probe.priv || d->chain1_affine.priv) return;
+    if (!d->xcc_probe.ok || !d->chain1_affine.ok || d->xcc_probe.priv || d->chain1_affine.priv || (d->duo_affine.ok && d->duo_affine.priv)) return;
     constexpr uint32_t BLOCKS = 1024;
     const size_t words = (size_t)2 * CHAIN_STREAMS * BLOCKS;
     uint32_t* out = nullptr;

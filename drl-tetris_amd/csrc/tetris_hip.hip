@@ -257,19 +257,32 @@ __device__ __forceinline__ void observe_emit(const KArgs& a, const Game<P>& g, i
 // wave of the previous launch published, and all state traffic is agent-scope.
 // OBS (tetris_step_rt_observe_dev): after the step every lane turns its own board into the packed observation — slot 0 if its
 // player is the one the game's next decision is for, slot 1 otherwise; rows 0..31 / 32..63 of the wave's LDS tile.
-template <int MODE, bool CHAIN = false, bool OBS = false>
-__global__ __launch_bounds__(CHAIN ? 64 : 256) void k_duo(KArgs a) {
+// AFFINE (with CHAIN; k_duo_affine, direct dispatch only): the XCD-affine hand-over of k_chain_affine — a wave's 32 games follow the XCD.
+template <int MODE, bool CHAIN, bool OBS, bool AFFINE>
+__device__ __forceinline__ void duo_body(const KArgs& a) {
     __shared__ __attribute__((aligned(16))) uint32_t s_shapes_all[4][SHAPE_WORDS];      // per-wave copy, no block barrier (see k_game)
     extern __shared__ __attribute__((aligned(16))) uint32_t s_duo_tile[];               // OBS: 4 waves x 64 rows x nw words
     uint32_t* s_shapes = s_shapes_all[threadIdx.x >> 6];
     const uint32_t shape_word = d_shape_table.s[threadIdx.x & 63];
     const int lane = threadIdx.x & 63, side = lane >> 5;
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    constexpr bool ROLL = MODE == M_ROLLOUT, AUTO = MODE == M_STEP_RT_AUTO;
+    constexpr int MEM = CHAIN ? (AFFINE ? MEM_AFFINE : MEM_AGENT) : MEM_STREAM;
+    if (CHAIN && a.steps < 0) { chain_census(a, lane == 0); return; }
+    if (AFFINE) {                        // (64-thread workgroups: one wave each; see chain_body)
+        uint32_t xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        xcc &= 0xFu;
+        if (blockIdx.x == 0 && lane == 0) ((volatile uint32_t*)a.status)[F_XCC0 + (a.xcd_slot & 3u)] = 0x100u | xcc;
+        if (xcc != ((a.xcd_base + blockIdx.x) & 7u)) {
+            if (lane == 0) ((volatile uint32_t*)a.status)[F_PLACE] = 1u;
+            return;
+        }
+        wave = (int)((blockIdx.x & ~7u) | xcc);
+        if (wave * 32 >= a.n) return;
+    }
     const int gi = wave * 32 + (lane & 31);
     const bool active = gi < a.n;
-    constexpr bool ROLL = MODE == M_ROLLOUT, AUTO = MODE == M_STEP_RT_AUTO;
-    constexpr int MEM = CHAIN ? MEM_AGENT : MEM_STREAM;
-    if (CHAIN && a.steps < 0) { chain_census(a, lane == 0); return; }
     Geo geo = geo_of(a);
     geo.P = 2;                           // compile-time stride factor for the hot loads
     const Ref gr = game_ref(geo, (size_t)gi, true);
@@ -402,7 +415,10 @@ __global__ __launch_bounds__(CHAIN ? 64 : 256) void k_duo(KArgs a) {
     }
     if (CHAIN) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every store (and counter atomic) of this wave has been acknowledged
-        if (lane == 0) st_agent(a.chain + (size_t)wave * CHAIN_STRIDE, a.epoch);
+        if (lane == 0) {
+            if (AFFINE) *(volatile uint32_t*)(a.chain + (size_t)wave * CHAIN_STRIDE) = a.epoch;
+            else st_agent(a.chain + (size_t)wave * CHAIN_STRIDE, a.epoch);
+        }
     }
     if (OBS) {
         const int pitch = a.H * NCOL / 4, first = wave * 32;
@@ -420,6 +436,9 @@ __global__ __launch_bounds__(CHAIN ? 64 : 256) void k_duo(KArgs a) {
         }
     }
 }
+template <int MODE, bool CHAIN = false, bool OBS = false>
+__global__ __launch_bounds__(CHAIN ? 64 : 256) void k_duo(KArgs a) { duo_body<MODE, CHAIN, OBS, false>(a); }
+__global__ __launch_bounds__(64) void k_duo_affine(KArgs a) { duo_body<M_ROLLOUT, true, false, true>(a); }
 
 template <int STAGE, bool TINT>
 __global__ __launch_bounds__(256) void k_split(KArgs a) {
@@ -2116,9 +2135,9 @@ static int rollout_direct(tetris_batch* b, aql::Device* dev, int launches, int s
     const int depth = b->chain_depth;
     // one-player batches on queues that deal their blocks round-robin over the XCDs: the XCD-affine kernel (k_chain_affine), whole groups
     // of eight workgroups, no cache maintenance between a queue's launches
-    const bool affine = b->P == 1 && b->use_affine && qs.affine_ok && dev->chain1_affine.ok && CHAIN_LANES == 64;
+    const bool affine = b->use_affine && qs.affine_ok && (b->P == 1 ? dev->chain1_affine.ok && CHAIN_LANES == 64 : dev->duo_affine.ok);
     b->last_affine = affine;
-    const aql::Kernel& kern = affine ? dev->chain1_affine : (b->P == 1 ? dev->chain1 : dev->duo);
+    const aql::Kernel& kern = affine ? (b->P == 1 ? dev->chain1_affine : dev->duo_affine) : (b->P == 1 ? dev->chain1 : dev->duo);
     uint32_t blocks = b->P == 1 ? (uint32_t)((b->N + CHAIN_LANES - 1) / CHAIN_LANES) : (uint32_t)((b->N + 31) / 32);
     if (affine) blocks = (blocks + 7u) & ~7u;
     const int wgroup = std::min(aql::SLOTS / 2 - 2, std::max(8, group / depth));
