@@ -300,6 +300,7 @@ def main():
     res = shard.run(args.steps, S)                    # exactly K timed launches
     counters, wall, ev_ms = res["counters"], res["wall_s"], res["event_ms"]
     direct = bool(shard.batch.rollout_was_direct())       # (asked now: the GPU-paced extra run below goes through the streams)
+    affine = bool(shard.batch.rollout_was_affine())       # the XCD-affine kernels (include/tetris_hip.h: tetris_set_xcd_affine)
     batch = shard
     # after the timed region, single GPU, chained single-step launches only: the same launches GPU-paced (the library parks its
     # streams behind a blocker kernel until all 512 launches are queued) — the period the GPU sustains when the host's launch
@@ -331,7 +332,8 @@ def main():
         launch_us_events = ev_ms * 1e3 / args.steps if ev_ms > 0 else None     # (the CPU rehearsal library has no events)
         lib_path = os.path.abspath(os.environ.get("BENCH_LIB_PATH") or ge.LIB)
         roofline = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "kernel": (("k_chain<1>" if P == 1 else "k_duo<M_ROLLOUT, true>") + " (chained launches: consecutive launches on "
+                    "kernel": (((("k_chain_affine<1>" if P == 1 else "k_duo_affine") + " — XCD-affine: a game block is stepped on the same XCD in every launch, its state stays in that XCD's L2 —")
+                                if affine else ("k_chain<1>" if P == 1 else "k_duo<M_ROLLOUT, true>")) + " (chained launches: consecutive launches on "
                                + ("three" if P == 1 else "two") + " queues / streams, each wave waits for its own predecessor's epoch word)") if chained
                               else ("k_duo<M_ROLLOUT>" if (P == 2 and S == 1) else f"k_game<{P}, M_ROLLOUT>"),
                     "launch_us": launch_us, "launch_us_events": launch_us_events, "clock": "wall (same clock as `value`)"}
@@ -348,7 +350,7 @@ def main():
             achieved = algo_bytes / (launch_us * 1e-6) / 1e9
             if achieved > HBM_PEAK_GBS:
                 roofline["frac_note"] = ("above 1: SURVEY 8(d)'s algorithmic bytes (192 B in + 192 B out per player-board) are a budget, not what the kernel "
-                                         "moves (measured `traffic` is lower), and the 20 MB state of 64k two-player games lives in the 256 MB Infinity Cache")
+                                         "moves, and the 20 MB state of 64k two-player games lives in the caches (the XCDs' L2s in the affine form, the 256 MB Infinity Cache otherwise)")
             roofline.update({"achieved": achieved, "frac": achieved / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": algo_bytes,
                              "frac_kernel": (algo_bytes / (launch_us_events * 1e-6) / 1e9 / HBM_PEAK_GBS) if launch_us_events else None})
             if gpu_paced_us:
@@ -360,7 +362,19 @@ def main():
             # command (profiles/pmc_passes.sh), corrected as MI355X_MICROARCH.md prescribes; the file is named next to the number
             pmc = os.path.join(ROOT, "profiles", "r03", f"pmc_p{P}_s{S}.json")
             traffic, source = None, None
-            if os.path.exists(pmc):
+            if affine:
+                # the affine kernels keep the state in the XCDs' L2s for the length of a call: what reaches the fabric per launch is no
+                # property of one dispatch (dirty lines leave at the call's last packet), and a --pmc run, whose dispatches are serialised with
+                # the tool's own packets between them, measures another regime (profiles/r03/pmc_p1_affine_summary.json: WRITE_SIZE median
+                # 36 KiB per dispatch).  The write-through kernel's measured figure is reported beside the null.
+                source = ("none: state is L2-resident across the launches of a call (XCD-affine kernel); per-dispatch PMC counters do not describe it — "
+                          "profiles/r03/pmc_p1_affine_summary.json; `traffic_write_through_kernel` is the measured figure of the non-affine kernel")
+                if os.path.exists(pmc):
+                    try:
+                        roofline["traffic_write_through_kernel"] = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                    except Exception:
+                        pass
+            elif os.path.exists(pmc):
                 try:
                     traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
                     source = (os.path.relpath(pmc, ROOT) + " (separate rocprofv3 --pmc passes of this command with the dispatches serialised, "

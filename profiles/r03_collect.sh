@@ -10,6 +10,7 @@ if [ -d $A ]; then
   cp $A/bench_p1_s1.json $A/bench_p1_s1_driver_flags.json $A/bench_p2_s1.json $A/bench_p1_s1_unchained.json $A/bench_p2_s1_unchained.json $A/bench_p1_s32.json $DST/
   cp $A/split_stages.json $A/dropin_api.json $A/dropin_breakdown.json $A/chain_period_from_trace_p1.json $A/chain_period_from_trace_p2.json $DST/
   cp $A/order_check_p1.txt $A/order_check_p2.txt $DST/
+  cp $A/bench_p1_s1_write_through.json $A/bench_p1_s1_driver_flags_write_through.json $A/bench_p2_s1_write_through.json $A/chain_soak.txt $DST/ 2>/dev/null || true
   cp $A/bench_p1_s1_streams.json $A/bench_p1_s1_driver_flags_streams.json $A/bench_p2_s1_streams.json $A/driver_flags_ab.txt $A/direct_vs_streams.txt $DST/ 2>/dev/null || true
   cp $A/pytest_gpu.log $DST/pytest_gpu.txt; cp $A/smoke.log $DST/smoke.txt
   cp $A/prof_p1.log $DST/bench_under_profiler_p1_s1.txt; cp $A/prof_p2.log $DST/bench_under_profiler_p2_s1.txt

@@ -13,6 +13,12 @@ timeout -k 10 200 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.
 timeout -k 10 300 python bench.py > $O/bench_p1_s1.json 2> $O/bench_p1_s1.err
 timeout -k 10 300 python bench.py --steps 20 --warmup 5 > $O/bench_p1_s1_driver_flags.json 2>/dev/null
 timeout -k 10 200 python bench.py --players 2 --cpu-seconds 0 > $O/bench_p2_s1.json 2>/dev/null
+# the same lines without the XCD-affine kernels (direct dispatch, write-through hand-over), then through hipLaunchKernel on streams
+TETRIS_AFFINE=0 timeout -k 10 300 python bench.py --cpu-seconds 0 > $O/bench_p1_s1_write_through.json 2>/dev/null
+TETRIS_AFFINE=0 timeout -k 10 300 python bench.py --steps 20 --warmup 5 --cpu-seconds 0 > $O/bench_p1_s1_driver_flags_write_through.json 2>/dev/null
+TETRIS_AFFINE=0 timeout -k 10 200 python bench.py --players 2 --cpu-seconds 0 > $O/bench_p2_s1_write_through.json 2>/dev/null
+{ timeout -k 10 300 python tests/tools/chain_soak.py 10000 1; timeout -k 10 300 python tests/tools/chain_soak.py 10000 2; } 2>&1 | grep -v amdgpu.ids > $O/chain_soak.txt
+cat $O/chain_soak.txt
 # the same lines with the launches going through hipLaunchKernel on streams instead of the batch's own queues
 TETRIS_DIRECT=0 timeout -k 10 300 python bench.py --cpu-seconds 0 > $O/bench_p1_s1_streams.json 2>/dev/null
 TETRIS_DIRECT=0 timeout -k 10 300 python bench.py --steps 20 --warmup 5 --cpu-seconds 0 > $O/bench_p1_s1_driver_flags_streams.json 2>/dev/null
