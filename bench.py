@@ -355,7 +355,8 @@ def main():
                              "frac_kernel": (algo_bytes / (launch_us_events * 1e-6) / 1e9 / HBM_PEAK_GBS) if launch_us_events else None})
             if gpu_paced_us:
                 roofline.update({"launch_us_gpu_paced": gpu_paced_us, "frac_gpu_paced": algo_bytes / (gpu_paced_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                                 "gpu_paced_note": "extra run AFTER the timed region: 512 launches queued behind a blocker kernel before the first starts "
+                                 "gpu_paced_note": ("NOT the timed kernel: the write-through kernel on HIP streams (the pre-queued call goes that way). " if affine else "") +
+                                                   "extra run AFTER the timed region: 512 launches queued behind a blocker kernel before the first starts "
                                                    "(HIP events); `value`, `launch_us` and `frac` above are the host-paced wall clock of the K timed launches "
                                                    "(on a host that launches faster than the GPU steps the two agree to a few per cent; a slower host shows in the wall clock only)"})
             # HBM traffic cannot be measured inside this process: it comes from separate rocprofv3 --pmc passes over this same

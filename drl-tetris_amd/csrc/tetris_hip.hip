@@ -2353,8 +2353,7 @@ int tetris_rollout_launch(tetris_batch* b, int launches, int steps_per_launch, u
         if (!(dev->ok && aql::make_queues(dev, why))) {
             b->direct_min = 0;
             if (getenv("TETRIS_TIMING")) fprintf(stderr, "[tetris] direct dispatch is off: %s\n", why.c_str());
-        } else if (launches >= b->direct_min) {
-            aql::calibrate_affine(dev);
+        } else if (aql::calibrate_affine(dev), launches >= b->direct_min) {       // (measured once, by whichever chained call comes first)
             if (b->home_async) { HIP_TRY(hipStreamSynchronize(home)); }      // what the batch's stream still holds comes first
             b->last_direct = true; b->direct_used = true;
             if (getenv("TETRIS_TIMING")) fprintf(stderr, "[tetris timing] call entry -> direct dispatch %.1f us\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_entry).count() * 1e6);

@@ -129,3 +129,43 @@ def test_xcd_affine_launches_equal_the_plain_hand_over_and_misplaced_launches_co
     _, want = ref.rollout_random(500, threads=THREADS)
     assert total.tolist() == want.tolist()
     _same(a, ref, n)
+
+
+def test_xcd_affine_state_survives_other_kernels_boundaries():
+    """While an affine call keeps its games' state dirty in the XCDs' L2s (no cache maintenance between its own launches), another
+    batch of the process steps, observes and copies on HIP streams from a second host thread — kernels whose starts invalidate and whose
+    ends write back the caches.  The affine batch must come out as the oracle's: a kernel boundary of somebody else never costs it data."""
+    import threading
+    n = 65536
+    seeds = orc.episode_seed(np.arange(n), 0)
+    eng, ref = engines.make("hip", n, 1, seeds=seeds), engines.make("oracle", n, 1, seeds=seeds)
+    other = engines.make("hip", 4096, 2, seeds=orc.episode_seed(np.arange(4096), 7))
+    other.set_chained(False)
+    stop = threading.Event()
+    laps = [0]
+
+    def noise():
+        rng = np.random.default_rng(3)
+        while not stop.is_set():
+            other.step_rt(rng.integers(0, 4, 4096).astype(np.uint8), rng.integers(0, 10, 4096).astype(np.uint8), np.zeros(4096, np.uint8))
+            other.observe(np.arange(0, 4096, 5, dtype=np.int32))
+            other.snapshot(np.arange(64, dtype=np.int32))
+            laps[0] += 1
+
+    t = threading.Thread(target=noise)
+    t.start()
+    try:
+        total, step = np.zeros(4, np.uint64), 0
+        for launches in (3000, 20, 2000):
+            c, _ = eng.rollout_random(launches, 1, first_step=step)
+            assert eng.rollout_was_affine()
+            total += c
+            step += launches
+    finally:
+        stop.set()
+        t.join()
+    assert laps[0] > 20                                    # the other batch really ran meanwhile
+    assert eng.take_errors() == 0
+    _, want = ref.rollout_random(step, threads=THREADS)
+    assert total.tolist() == want.tolist()
+    _same(eng, ref, n)
