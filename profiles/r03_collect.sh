@@ -17,6 +17,7 @@ if [ -d $A ]; then
   cp "$(newest $A/prof_p1 '*kernel_stats.csv')" $DST/kernel_stats_p1_s1.csv
   cp "$(newest $A/prof_p2 '*kernel_stats.csv')" $DST/kernel_stats_p2_s1.csv
   cp "$(newest $A/prof_p1_unchained '*kernel_stats.csv')" $DST/kernel_stats_p1_s1_unchained.csv
+  [ -d $A/prof_p1_affine ] && cp "$(newest $A/prof_p1_affine '*kernel_stats.csv')" $DST/kernel_stats_p1_s1_affine.csv
   cp "$(newest $A/prof_p2_unchained '*kernel_stats.csv')" $DST/kernel_stats_p2_s1_unchained.csv
   cp "$(newest $A/prof_split '*kernel_stats.csv')" $DST/kernel_stats_split.csv
   for c in enum_planar observe step_auto_1p step_auto_2p step_obs_1p step_obs_2p; do

@@ -34,6 +34,8 @@ prof() { (cd /tmp; export TMPDIR=/tmp; timeout -k 10 300 rocprofv3 --kernel-trac
 prof prof_p1 $R/bench.py --cpu-seconds 0
 prof prof_p2 $R/bench.py --cpu-seconds 0 --players 2
 python profiles/chain_period_from_trace.py $O/prof_p1 $O/chain_period_from_trace_p1.json > /dev/null
+# (under the profiler the launches stay on the streams: forced onto the library's queues — TETRIS_DIRECT_UNDER_TOOLS=1 — the --pmc passes of
+# r03_final_c.sh went through, a --kernel-trace --stats run died inside the tool's doorbell handler: profiles/r03/direct_dispatch.txt (5))
 python profiles/chain_period_from_trace.py $O/prof_p2 $O/chain_period_from_trace_p2.json > /dev/null
 grep -h period_us_of $O/chain_period_from_trace_p1.json $O/chain_period_from_trace_p2.json
 export TETRIS_NO_CHAIN=1 TETRIS_GRAPH=1
