@@ -338,7 +338,7 @@ def main():
                               else ("k_duo<M_ROLLOUT>" if (P == 2 and S == 1) else f"k_game<{P}, M_ROLLOUT>"),
                     "launch_us": launch_us, "launch_us_events": launch_us_events, "clock": "wall (same clock as `value`)"}
         if chained:
-            roofline["dispatch"] = ("direct: the K launches are AQL packets the library writes into HSA queues of the batch's own (include/tetris_hip.h: "
+            roofline["dispatch"] = ("direct: the K launches are AQL packets the library writes into HSA queues of its own (three per GPU; include/tetris_hip.h: "
                                     "tetris_set_direct_dispatch); `launch_us_events` = (end of the last dispatch - start of the first) / K from the packets' own timestamps"
                                     if direct else "streams: hipLaunchKernel on the batch's chain streams; `launch_us_events` from HIP events attached to the first and last kernel")
             roofline["launch_us_is"] = ("the launch PERIOD: consecutive launches overlap (a wave of launch E starts as soon as the same wave of "
